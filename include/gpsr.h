@@ -1,0 +1,171 @@
+/*
+ * gpsr.h -- C ABI of the MI355X (gfx950) batched Gaussian-process
+ * super-resolution engine.
+ *
+ * The reference (fynsta/Super-resolution) is pure Python on GPyTorch and has no
+ * FFI of its own; each entry point below names the reference code it replaces
+ * (file:line in the reference tree).  SURVEY.md 8(b) is the contract:
+ *   - extern "C", plain pointers and sizes, no torch types;
+ *   - every function returns int: 0 ok, <0 bad argument / HIP error,
+ *     >0 number of GPs whose factorisation hit a non-positive pivot
+ *     (details in the caller's flags[B]);
+ *   - the caller owns every buffer (device pointers), including the workspace;
+ *   - every launch goes on the hipStream_t passed in (as void*); calls are
+ *     asynchronous and never synchronise the device.
+ *
+ * Data are float64 images / features; hyper-parameters are the float32 RAW
+ * (unconstrained) values GPyTorch keeps:  raw[b][0..3] =
+ *   { likelihood.noise_covar.raw_noise, mean_module.raw_constant,
+ *     covar_module.raw_outputscale, covar_module.base_kernel.raw_lengthscale
+ *     (raw_variance for the linear kernel) }
+ * with noise = softplus(raw)+1e-4 and the others softplus(raw).
+ */
+#ifndef GPSR_H
+#define GPSR_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* kernel_id: reference kernels.py:7-13 (get_kernel_name tags kernels.py:26-47) */
+enum {
+  GPSR_KERNEL_RBF = 0,      /* rbf_kernel          "RBF"      */
+  GPSR_KERNEL_MATERN12 = 1, /* exponential_kernel  "matern12" */
+  GPSR_KERNEL_MATERN32 = 2, /* matern32_kernel     "matern32" */
+  GPSR_KERNEL_MATERN52 = 3, /* matern52_kernel     "matern52" */
+  GPSR_KERNEL_LINEAR = 4    /* linear_kernel       "linear"   */
+};
+
+/* PatchInterpolationMode, image_patches.py:4-6 */
+enum { GPSR_COMBINE_AVERAGE = 0, GPSR_COMBINE_BILINEAR = 1 };
+
+#define GPSR_BLOCK 112 /* pivot-block / tile edge of the batched inversion */
+
+/* Library version string ("gpsr <x.y> gfx950"). */
+const char* gpsr_version(void);
+
+/* Last HIP error text seen by this thread's most recent failing call. */
+const char* gpsr_last_error(void);
+
+/* Padded matrix order used for n training points: n rounded up to GPSR_BLOCK. */
+int gpsr_padded_n(int n);
+
+/*
+ * K1 gather.  Replaces PatchIterator.__next__ (image_patches.py:92-107) plus the
+ * feature list-comprehensions of gprsr.py:148,150,192 / extract_neighbors
+ * (gprsr.py:34-35) for B patches at once.
+ *   train_in, train_tgt : [H][W] f64      test_in : [H*s][W*s] f64
+ *   locs  : [B][2] int32 (row, col) LR patch corners (PatchHandler.patch_locations)
+ *   tidx  : [nt] int32 per-axis training indices inside the LR patch
+ *           (range(1,p-1), or the grid of gprsr.py:140); n = nt*nt
+ *   X  : [B][n][8]   y : [B][n]   Xs : [B][m][8],  m = (p*s-2)^2
+ * Feature order is that of gprsr.py:35.
+ */
+int gpsr_gather(const double* train_in, const double* train_tgt, const double* test_in,
+                int H, int W, int s, int p, const int32_t* locs, int B,
+                const int32_t* tidx, int nt,
+                double* X, double* y, double* Xs, void* stream);
+
+/*
+ * Per-patch initial hyper-parameters, gprsr.py:162-174: noise=1e-3,
+ * constant=mean(y.float()); RBF: lengthscale=.223, outputscale=var(y.float());
+ * other kernels: raw_outputscale/raw_lengthscale = init_os_ls[0..1], or, when
+ * carry != NULL, the two floats at carry[2], carry[3] (device pointer to a
+ * previous GP's raw[4] -- the reference's warm-start chain).
+ */
+int gpsr_init_hypers(const double* y, int B, int n, int kernel_id,
+                     float init_raw_os, float init_raw_ls, const float* carry,
+                     float* raw, void* stream);
+
+/*
+ * K2 covariance.  K[b] = outputscale * k(X_b, X_b) + noise * I  as the lower
+ * block-triangle (GPSR_BLOCK tiles, diagonal tiles full) of a [N][N] matrix,
+ * N = gpsr_padded_n(n); rows/cols >= n are identity.  Replaces GPyTorch's
+ * kernel forward + likelihood noise reached from kernels.py:21-24 and
+ * gprsr.py:183-184.   X : [B][n][d]   raw : [B][4]   K : [B][N][N]
+ */
+int gpsr_covariance(const double* X, int B, int n, int d, int kernel_id,
+                    const float* raw, double* K, void* stream);
+
+/*
+ * In-place batched SPD inversion by blocked symmetric Gauss-Jordan sweeps
+ * (MFMA f64 trailing updates).  On return A[b] holds -inv(A[b]) in the lower
+ * block-triangle, logdet[b] = log det A[b].  Workspace: gpsr_invert_workspace_bytes.
+ * This is the factorisation the fit uses instead of GPyTorch's dense Cholesky
+ * (linear_operator psd_safe_cholesky reached from gprsr.py:184-185).
+ */
+size_t gpsr_invert_workspace_bytes(int B, int n);
+int gpsr_invert(double* A, int B, int n, double* logdet, int32_t* flags,
+                void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * K3+K4 fit.  Replaces the training loop gprsr.py:176-186 (agpr.py:75-83):
+ * `iters` Adam steps (lr, betas .9/.999, eps 1e-8, float32 state) on
+ * -ExactMarginalLogLikelihood/n, then one more factorisation at the final
+ * hyper-parameters giving alpha = (K+noise I)^-1 (y - c) for gprsr.py:195.
+ *   X : [B][n][d]  y : [B][n]  raw : [B][4] in/out
+ *   alpha : [B][N] out (entries >= n are 0)   loss : [B] out or NULL (last evaluated loss)
+ *   flags : [B] int32 out (non-zero: a pivot was <= 0 at some iteration)
+ */
+size_t gpsr_fit_workspace_bytes(int B, int n, int d);
+int gpsr_fit(const double* X, const double* y, int B, int n, int d, int kernel_id,
+             float* raw, int iters, float lr, double* alpha, double* loss, int32_t* flags,
+             void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * One evaluation of the loss and of d loss / d raw (no Adam step), for tests:
+ * what loss.backward() leaves in .grad at gprsr.py:185.   grad : [B][4] float32
+ */
+int gpsr_loss_grad(const double* X, const double* y, int B, int n, int d, int kernel_id,
+                   const float* raw, double* loss, float* grad, int32_t* flags,
+                   void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * K5 predictive mean, fused (K(X*,X) is never materialised):
+ * out[b][t] = c + outputscale * sum_i k(Xs[b][t], X[b][i]) alpha[b][i].
+ * Replaces likelihood(model(test_x)).mean, gprsr.py:195.  d must be 8.
+ *   alpha : [B][N] (N = gpsr_padded_n(n))   out : [B][m]
+ */
+int gpsr_predict(const double* X, const double* Xs, const double* alpha, const float* raw,
+                 int B, int n, int m, int kernel_id, double* out, void* stream);
+
+/*
+ * K6 recombination.  Replaces the write-back gprsr.py:199-202,
+ * PatchHandler.combine_patches (image_patches.py:44-76) and the clip gprsr.py:208.
+ * Patches lie on the grid rows[nr] x cols[nc] (LR corners, row-major patch
+ * order, duplicates allowed); pred holds their predicted interiors [nr*nc][m];
+ * the 1-px rim of a patch is the test image itself and is only used where it
+ * lies on the image border.  With test_in == NULL, pred instead holds whole
+ * patches [nr*nc][P][P] (rim included), which is the shape combine_patches
+ * itself is handed.  Additions happen in patch order, so the result is
+ * bit-identical to the reference loop.   out : [H*s][W*s], clipped to [0,1]
+ * when clip != 0 (gprsr.py:208; combine_patches itself does not clip).
+ */
+int gpsr_combine(const double* pred, const double* test_in, int H, int W, int s, int p,
+                 const int32_t* rows, int nr, const int32_t* cols, int nc, int mode, int clip,
+                 double* out, void* stream);
+
+/*
+ * K7 AGPR: the linear-kernel posterior mean is affine in the 7x7 window:
+ * w[49] = outputscale * variance * X^T alpha.  gpsr_agpr_weights builds w from
+ * a fitted model (agpr.py:58,176), gpsr_agpr_filter applies
+ * out[i][j] = bias + sum w * window(img, i, j) to the interior of a [Hs][Ws]
+ * image and copies the `pad`-px rim (agpr.py:165-185).  Windows are cast to
+ * float32 first, as agpr.py:170 does.
+ */
+int gpsr_agpr_weights(const double* X, const double* alpha, const float* raw, int n, int d,
+                      double* w, void* stream);
+int gpsr_agpr_filter(const double* img, int Hs, int Ws, int L, const double* w, const float* raw,
+                     double* out, void* stream);
+
+/* Self-test of the f64 MFMA operand/accumulator lane maps: D = A(16x4) B(4x16),
+ * plain row-major inputs and output.  Used by tests only. */
+int gpsr_selftest_mfma(const double* A, const double* Bm, double* D, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* GPSR_H */

@@ -1,0 +1,81 @@
+"""ctypes binding of libgpsr.so (the C ABI declared in include/gpsr.h).
+
+The HIP library is the product path: there is NO CPU fallback.  If the shared
+object is missing or cannot be loaded, every compute entry point raises.
+"""
+import ctypes
+import os
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgpsr.so")
+SRC = os.path.join(_HERE, "csrc", "gpsr_api.hip")
+HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-ffp-contract=off"]
+
+_lib = None
+
+c_void_p, c_int, c_float, c_size_t = ctypes.c_void_p, ctypes.c_int, ctypes.c_float, ctypes.c_size_t
+
+# name -> (restype, argtypes); must list every symbol include/gpsr.h declares
+SIGNATURES = {
+    "gpsr_version": (ctypes.c_char_p, []),
+    "gpsr_last_error": (ctypes.c_char_p, []),
+    "gpsr_padded_n": (c_int, [c_int]),
+    "gpsr_gather": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4),
+    "gpsr_init_hypers": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "gpsr_covariance": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gpsr_invert_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "gpsr_invert": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gpsr_fit_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gpsr_fit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float,
+                         c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gpsr_loss_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
+                               c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gpsr_predict": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p]),
+    "gpsr_combine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
+                             c_int, c_int, c_void_p, c_void_p]),
+    "gpsr_agpr_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
+    "gpsr_agpr_filter": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gpsr_selftest_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+}
+
+
+def build(force=False):
+    """Compile csrc/gpsr_api.hip for gfx950 into libgpsr.so (in-tree)."""
+    srcs = [SRC, os.path.join(_HERE, "csrc", "gpsr_kernels.hpp"),
+            os.path.join(os.path.dirname(_HERE), "include", "gpsr.h")]
+    if not force and os.path.exists(LIB_PATH) and all(
+            os.path.getmtime(LIB_PATH) >= os.path.getmtime(s) for s in srcs):
+        return LIB_PATH
+    cmd = [HIPCC] + HIPCC_FLAGS + ["-o", LIB_PATH, SRC]
+    subprocess.run(cmd, check=True, cwd=_HERE)
+    return LIB_PATH
+
+
+def load():
+    """Load libgpsr.so; raises if it is absent (no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP extension is the only compute path "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype, fn.argtypes = res, args
+    _lib = lib
+    return lib
+
+
+class GpsrError(RuntimeError):
+    pass
+
+
+def check(rc, what):
+    """Negative status -> exception; positive = number of flagged GPs (returned)."""
+    if rc < 0:
+        raise GpsrError(f"{what} failed ({rc}): {load().gpsr_last_error().decode()}")
+    return rc

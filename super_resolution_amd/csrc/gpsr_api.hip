@@ -1,0 +1,334 @@
+// gpsr_api.hip -- C ABI (include/gpsr.h) over the gfx950 kernels.  No torch types,
+// no allocation: every buffer, the workspace included, belongs to the caller.
+#include "gpsr_kernels.hpp"
+#include "../../include/gpsr.h"
+
+#include <math.h>
+#include <stdio.h>
+#include <string.h>
+
+static thread_local char g_err[256] = "";
+
+static int hip_fail(hipError_t e, const char* where) {
+  snprintf(g_err, sizeof(g_err), "%s: %s", where, hipGetErrorString(e));
+  return -2;
+}
+static int arg_fail(const char* what) {
+  snprintf(g_err, sizeof(g_err), "bad argument: %s", what);
+  return -1;
+}
+#define CHECK_LAUNCH(where)                                 \
+  do {                                                      \
+    hipError_t e_ = hipGetLastError();                      \
+    if (e_ != hipSuccess) return hip_fail(e_, where);       \
+  } while (0)
+
+static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
+
+extern "C" const char* gpsr_version(void) { return "gpsr 0.1 gfx950"; }
+extern "C" const char* gpsr_last_error(void) { return g_err; }
+extern "C" int gpsr_padded_n(int n) { return ((n + NB - 1) / NB) * NB; }
+
+// ---------------------------------------------------------------- gather
+extern "C" int gpsr_gather(const double* train_in, const double* train_tgt, const double* test_in,
+                           int H, int W, int s, int p, const int32_t* locs, int B,
+                           const int32_t* tidx, int nt, double* X, double* y, double* Xs, void* stream) {
+  if (B <= 0) return 0;
+  if (!train_in || !train_tgt || !test_in || !locs || !tidx || !X || !y || !Xs) return arg_fail("null pointer");
+  if (p < 3 || s < 1 || p > H || p > W || nt < 1 || nt > p - 2) return arg_fail("patch geometry");
+  const int n = nt * nt, m = (p * s - 2) * (p * s - 2);
+  const int total = 9 * n + 8 * m;
+  int gx = (total + 255) / 256; if (gx > 64) gx = 64;
+  hipLaunchKernelGGL(k_gather, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, train_in, train_tgt, test_in,
+                     H, W, s, p, locs, tidx, nt, X, y, Xs);
+  CHECK_LAUNCH("k_gather");
+  return 0;
+}
+
+// ---------------------------------------------------------------- init
+static float inv_softplus_host(float x) { return x + logf(-expm1f(-x)); }
+
+extern "C" int gpsr_init_hypers(const double* y, int B, int n, int kernel_id, float init_raw_os,
+                                float init_raw_ls, const float* carry, float* raw, void* stream) {
+  if (B <= 0) return 0;
+  if (!y || !raw || n < 2) return arg_fail("init_hypers");
+  if (kernel_id < 0 || kernel_id > 4) return arg_fail("kernel_id");
+  const float raw_noise0 = inv_softplus_host(0.001f - 1e-4f);
+  const float raw_ls_rbf = inv_softplus_host(0.223f);
+  hipLaunchKernelGGL(k_init_hypers, dim3(B), dim3(256), 0, (hipStream_t)stream, y, n, kernel_id, raw_noise0,
+                     raw_ls_rbf, init_raw_os, init_raw_ls, carry, raw);
+  CHECK_LAUNCH("k_init_hypers");
+  return 0;
+}
+
+// ---------------------------------------------------------------- covariance
+static size_t build_lds(int d) { return (size_t)2 * NB * (d + 1) * sizeof(double); }
+
+static int launch_build(const double* X, int B, int n, int N, int d, int kid, const float* raw, double* A,
+                        double* logdet, hipStream_t st) {
+  const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2, total = ntri * B;
+  const size_t lds = build_lds(d);
+#define BUILD(K) hipLaunchKernelGGL((k_build<K>), dim3(total), dim3(256), lds, st, X, raw, A, n, N, d, ntri, total, logdet)
+  switch (kid) {
+    case K_RBF: BUILD(K_RBF); break;
+    case K_M12: BUILD(K_M12); break;
+    case K_M32: BUILD(K_M32); break;
+    case K_M52: BUILD(K_M52); break;
+    default: BUILD(K_LIN); break;
+  }
+#undef BUILD
+  CHECK_LAUNCH("k_build");
+  return 0;
+}
+
+extern "C" int gpsr_covariance(const double* X, int B, int n, int d, int kernel_id, const float* raw,
+                               double* K, void* stream) {
+  if (B <= 0) return 0;
+  if (!X || !raw || !K) return arg_fail("null pointer");
+  if (n < 1 || d < 1 || d > 64 || kernel_id < 0 || kernel_id > 4) return arg_fail("covariance shape");
+  return launch_build(X, B, n, gpsr_padded_n(n), d, kernel_id, raw, K, nullptr, (hipStream_t)stream);
+}
+
+// ---------------------------------------------------------------- inversion
+struct InvWs { double *Wn, *Wo, *P; };
+
+static size_t inv_ws_bytes(int B, int N) {
+  return 2 * align256((size_t)B * NB * N * 8) + align256((size_t)B * NB * NB * 8);
+}
+static InvWs inv_ws_carve(char* base, int B, int N) {
+  InvWs w;
+  w.Wn = (double*)base; base += align256((size_t)B * NB * N * 8);
+  w.Wo = (double*)base; base += align256((size_t)B * NB * N * 8);
+  w.P = (double*)base;
+  return w;
+}
+
+// sweeps every pivot block of B matrices; logdet must have been zeroed
+static int launch_sweeps(double* A, int B, int N, const InvWs& w, double* logdet, int32_t* flags, hipStream_t st) {
+  const int nblk = N / NB;
+  for (int k = 0; k < nblk; ++k) {
+    hipLaunchKernelGGL(k_pivot, dim3(B), dim3(MM_THREADS), 0, st, A, N, k, w.P, logdet, flags);
+    CHECK_LAUNCH("k_pivot");
+    if (nblk > 1) {
+      const int tp = (nblk - 1) * B;
+      hipLaunchKernelGGL(k_panel, dim3(tp), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.P, w.Wn, w.Wo, tp);
+      CHECK_LAUNCH("k_panel");
+      const int ntri1 = (nblk - 1) * nblk / 2, tu = ntri1 * B;
+      hipLaunchKernelGGL(k_update, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wn, w.Wo, ntri1, tu);
+      CHECK_LAUNCH("k_update");
+    }
+  }
+  return 0;
+}
+
+extern "C" size_t gpsr_invert_workspace_bytes(int B, int n) {
+  if (B <= 0 || n <= 0) return 0;
+  return inv_ws_bytes(B, gpsr_padded_n(n));
+}
+
+extern "C" int gpsr_invert(double* A, int B, int n, double* logdet, int32_t* flags, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (B <= 0) return 0;
+  if (!A || !logdet || !flags || !workspace) return arg_fail("null pointer");
+  if (n % NB != 0) return arg_fail("gpsr_invert needs n == gpsr_padded_n(n)");
+  if (workspace_bytes < inv_ws_bytes(B, n)) return arg_fail("workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(logdet, 0, (size_t)B * 8, st);
+  if (e != hipSuccess) return hip_fail(e, "memset logdet");
+  e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
+  if (e != hipSuccess) return hip_fail(e, "memset flags");
+  InvWs w = inv_ws_carve((char*)workspace, B, n);
+  return launch_sweeps(A, B, n, w, logdet, flags, st);
+}
+
+// ---------------------------------------------------------------- fit
+struct FitWs {
+  double* A; InvWs inv; double *stats1, *stats2, *logdet; float *m1, *m2;
+};
+static size_t fit_ws_bytes(int B, int N) {
+  const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2;
+  return align256((size_t)B * N * N * 8) + inv_ws_bytes(B, N) + align256((size_t)B * nblk * 4 * 8) +
+         align256((size_t)B * ntri * 2 * 8) + align256((size_t)B * 8) + 2 * align256((size_t)B * 4 * 4);
+}
+static FitWs fit_ws_carve(char* base, int B, int N) {
+  const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2;
+  FitWs w;
+  w.A = (double*)base; base += align256((size_t)B * N * N * 8);
+  w.inv = inv_ws_carve(base, B, N); base += inv_ws_bytes(B, N);
+  w.stats1 = (double*)base; base += align256((size_t)B * nblk * 4 * 8);
+  w.stats2 = (double*)base; base += align256((size_t)B * ntri * 2 * 8);
+  w.logdet = (double*)base; base += align256((size_t)B * 8);
+  w.m1 = (float*)base; base += align256((size_t)B * 4 * 4);
+  w.m2 = (float*)base;
+  return w;
+}
+
+extern "C" size_t gpsr_fit_workspace_bytes(int B, int n, int d) {
+  (void)d;
+  if (B <= 0 || n <= 0) return 0;
+  return fit_ws_bytes(B, gpsr_padded_n(n));
+}
+
+static int launch_grad2(const FitWs& w, const double* X, const float* raw, const double* alpha, int B, int n,
+                        int N, int d, int kid, hipStream_t st) {
+  const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2, total = ntri * B;
+  const size_t lds = build_lds(d) + 2 * NB * sizeof(double);
+#define G2(K) hipLaunchKernelGGL((k_grad2<K>), dim3(total), dim3(256), lds, st, w.A, X, raw, alpha, n, N, d, ntri, total, w.stats2)
+  switch (kid) {
+    case K_RBF: G2(K_RBF); break;
+    case K_M12: G2(K_M12); break;
+    case K_M32: G2(K_M32); break;
+    case K_M52: G2(K_M52); break;
+    default: G2(K_LIN); break;
+  }
+#undef G2
+  CHECK_LAUNCH("k_grad2");
+  return 0;
+}
+
+// K build + inversion + alpha (+ gradient statistics when with_grad)
+static int eval_once(const FitWs& w, const double* X, const double* y, const float* raw, double* alpha,
+                     int32_t* flags, int B, int n, int N, int d, int kid, bool with_grad, hipStream_t st) {
+  int rc = launch_build(X, B, n, N, d, kid, raw, w.A, w.logdet, st);
+  if (rc) return rc;
+  rc = launch_sweeps(w.A, B, N, w.inv, w.logdet, flags, st);
+  if (rc) return rc;
+  const int nblk = N / NB;
+  const size_t lds1 = (size_t)(N + 5 * NB + 32) * sizeof(double);
+  hipLaunchKernelGGL(k_grad1, dim3(nblk, B), dim3(MM_THREADS), lds1, st, w.A, N, n, nblk, y, raw, alpha, w.stats1);
+  CHECK_LAUNCH("k_grad1");
+  if (with_grad) return launch_grad2(w, X, raw, alpha, B, n, N, d, kid, st);
+  return 0;
+}
+
+static int check_fit_args(const double* X, const double* y, int B, int n, int d, int kid, const void* ws,
+                          size_t wsb) {
+  if (!X || !y || !ws) return arg_fail("null pointer");
+  if (n < 2 || d < 1 || d > 64 || kid < 0 || kid > 4) return arg_fail("fit shape / kernel_id");
+  if (gpsr_padded_n(n) > 16 * NB) return arg_fail("n too large (max 1792)");
+  if (wsb < fit_ws_bytes(B, gpsr_padded_n(n))) return arg_fail("workspace too small");
+  return 0;
+}
+
+extern "C" int gpsr_fit(const double* X, const double* y, int B, int n, int d, int kernel_id, float* raw,
+                        int iters, float lr, double* alpha, double* loss, int32_t* flags, void* workspace,
+                        size_t workspace_bytes, void* stream) {
+  if (B <= 0) return 0;
+  int rc = check_fit_args(X, y, B, n, d, kernel_id, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!raw || !alpha || !flags || iters < 0) return arg_fail("fit outputs");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = gpsr_padded_n(n), nblk = N / NB, ntri = nblk * (nblk + 1) / 2;
+  FitWs w = fit_ws_carve((char*)workspace, B, N);
+  hipError_t e = hipMemsetAsync(w.m1, 0, 2 * align256((size_t)B * 16), st);
+  if (e != hipSuccess) return hip_fail(e, "memset adam state");
+  e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
+  if (e != hipSuccess) return hip_fail(e, "memset flags");
+  const double b1 = 0.9, b2 = 0.999;
+  for (int it = 1; it <= iters; ++it) {
+    rc = eval_once(w, X, y, raw, alpha, flags, B, n, N, d, kernel_id, true, st);
+    if (rc) return rc;
+    const double bc1 = 1.0 - pow(b1, it), bc2 = 1.0 - pow(b2, it);
+    const float step_size = (float)((double)lr / bc1);
+    const float bc2_sqrt = (float)sqrt(bc2);
+    hipLaunchKernelGGL(k_adam, dim3((B + 63) / 64), dim3(64), 0, st, raw, w.m1, w.m2, w.stats1, w.stats2, w.logdet,
+                       B, n, nblk, ntri, loss, (float*)nullptr, 1, step_size, bc2_sqrt, (float)(1.0 - b1),
+                       (float)b2, (float)(1.0 - b2), 1e-8f);
+    CHECK_LAUNCH("k_adam");
+  }
+  // final factorisation at the post-step hyper-parameters -> alpha for the predictive mean
+  return eval_once(w, X, y, raw, alpha, flags, B, n, N, d, kernel_id, false, st);
+}
+
+extern "C" int gpsr_loss_grad(const double* X, const double* y, int B, int n, int d, int kernel_id,
+                              const float* raw, double* loss, float* grad, int32_t* flags, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+  if (B <= 0) return 0;
+  int rc = check_fit_args(X, y, B, n, d, kernel_id, workspace, workspace_bytes);
+  if (rc) return rc;
+  if (!raw || !loss || !grad || !flags) return arg_fail("loss_grad outputs");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = gpsr_padded_n(n), nblk = N / NB, ntri = nblk * (nblk + 1) / 2;
+  FitWs w = fit_ws_carve((char*)workspace, B, N);
+  hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
+  if (e != hipSuccess) return hip_fail(e, "memset flags");
+  // alpha scratch: reuse the (unused here) Wn panel tail?  No: keep it simple, alpha lives in stats-free space of Wo.
+  double* alpha = w.inv.Wo;  // [B][N] fits in [B][NB][N]; Wo is dead after the sweeps
+  rc = eval_once(w, X, y, raw, alpha, flags, B, n, N, d, kernel_id, true, st);
+  if (rc) return rc;
+  hipLaunchKernelGGL(k_adam, dim3((B + 63) / 64), dim3(64), 0, st, (float*)raw, w.m1, w.m2, w.stats1, w.stats2,
+                     w.logdet, B, n, nblk, ntri, loss, grad, 0, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f);
+  CHECK_LAUNCH("k_adam(eval)");
+  return 0;
+}
+
+// ---------------------------------------------------------------- predict
+extern "C" int gpsr_predict(const double* X, const double* Xs, const double* alpha, const float* raw, int B,
+                            int n, int m, int kernel_id, double* out, void* stream) {
+  if (B <= 0 || m <= 0) return 0;
+  if (!X || !Xs || !alpha || !raw || !out) return arg_fail("null pointer");
+  if (kernel_id < 0 || kernel_id > 4) return arg_fail("kernel_id");
+  if (n < 1 || (size_t)n * 9 * 8 > 150 * 1024) return arg_fail("n too large for predict");
+  const int N = gpsr_padded_n(n);
+  const size_t lds = (size_t)n * 9 * sizeof(double);
+  dim3 grid((m + 256 * PRED_TP - 1) / (256 * PRED_TP), B);
+  hipStream_t st = (hipStream_t)stream;
+#define PR(K)                                                                                               \
+  do {                                                                                                      \
+    if (lds > 48 * 1024) {                                                                                  \
+      hipError_t e = hipFuncSetAttribute((const void*)k_predict<K>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                         (int)lds);                                                         \
+      if (e != hipSuccess) return hip_fail(e, "predict lds attr");                                          \
+    }                                                                                                       \
+    hipLaunchKernelGGL((k_predict<K>), grid, dim3(256), lds, st, X, Xs, alpha, raw, n, N, m, out);          \
+  } while (0)
+  switch (kernel_id) {
+    case K_RBF: PR(K_RBF); break;
+    case K_M12: PR(K_M12); break;
+    case K_M32: PR(K_M32); break;
+    case K_M52: PR(K_M52); break;
+    default: PR(K_LIN); break;
+  }
+#undef PR
+  CHECK_LAUNCH("k_predict");
+  return 0;
+}
+
+// ---------------------------------------------------------------- combine
+extern "C" int gpsr_combine(const double* pred, const double* test_in, int H, int W, int s, int p,
+                            const int32_t* rows, int nr, const int32_t* cols, int nc, int mode, int clip,
+                            double* out, void* stream) {
+  if (!pred || !rows || !cols || !out) return arg_fail("null pointer");
+  if (nr < 1 || nc < 1 || p < 3 || s < 1 || (mode != 0 && mode != 1)) return arg_fail("combine geometry");
+  const size_t total = (size_t)H * s * W * s;
+  hipLaunchKernelGGL(k_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred,
+                     test_in, H, W, s, p, rows, nr, cols, nc, mode, clip, out);
+  CHECK_LAUNCH("k_combine");
+  return 0;
+}
+
+// ---------------------------------------------------------------- AGPR
+extern "C" int gpsr_agpr_weights(const double* X, const double* alpha, const float* raw, int n, int d,
+                                 double* w, void* stream) {
+  if (!X || !alpha || !raw || !w || d < 1 || d > 64 || n < 1) return arg_fail("agpr_weights");
+  hipLaunchKernelGGL(k_agpr_weights, dim3(1), dim3(64), 0, (hipStream_t)stream, X, alpha, raw, n, d, w);
+  CHECK_LAUNCH("k_agpr_weights");
+  return 0;
+}
+
+extern "C" int gpsr_agpr_filter(const double* img, int Hs, int Ws, int L, const double* w, const float* raw,
+                                double* out, void* stream) {
+  if (!img || !w || !raw || !out || L < 1 || (L & 1) == 0 || L > 8 || Hs < L || Ws < L) return arg_fail("agpr_filter");
+  const size_t total = (size_t)Hs * Ws;
+  hipLaunchKernelGGL(k_agpr_filter, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, img,
+                     Hs, Ws, L, w, raw, out);
+  CHECK_LAUNCH("k_agpr_filter");
+  return 0;
+}
+
+extern "C" int gpsr_selftest_mfma(const double* A, const double* Bm, double* D, void* stream) {
+  if (!A || !Bm || !D) return arg_fail("null pointer");
+  hipLaunchKernelGGL(k_selftest_mfma, dim3(1), dim3(64), 0, (hipStream_t)stream, A, Bm, D);
+  CHECK_LAUNCH("k_selftest_mfma");
+  return 0;
+}

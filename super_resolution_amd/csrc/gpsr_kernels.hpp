@@ -1,0 +1,716 @@
+// gpsr_kernels.hpp -- device code of the batched GP super-resolution engine (gfx950 only).
+//
+// Layout conventions
+//   A      [B][N][N] f64 row-major, N = nblk*NB.  Only block (I,J) with I>=J is
+//          maintained ("lower block-triangle"); diagonal blocks are kept full.
+//   Wn, Wo [B][NB][N]  k-major panels of the current pivot step:
+//          Wo[kk][r] = old A[r][k0+kk],  Wn[kk][r] = -(A_.k P)[r][kk]
+//   Pbuf   [B][NB][NB] inverse of the current pivot block
+//   raw    [B][4] f32  raw hyper-parameters (noise, const, outputscale, lengthscale)
+//
+// Inversion = blocked symmetric Gauss-Jordan sweep (Goodnight's SWP operator):
+//   for each pivot block k:  P = A_kk^-1 ; A_ik <- A_ik P (i != k) ; A_kk <- -P ;
+//                            A_ij <- A_ij - A_ik P A_kj  (i,j != k)
+// after all pivots A = -A^-1 and sum log(pivots) = log det A.  Total work n^3
+// flops, all of it in 112x112x112 f64 MFMA tile products.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#define NB 112          // pivot block == tile edge
+#define NBT 7           // NB / 16 : MFMA tiles per edge == waves per workgroup
+#define MM_THREADS 448  // 64 * NBT
+#define KC 16           // k-chunk staged through LDS
+#define LDS_LD 113      // padded leading dimension of staged chunks
+
+typedef double v4d __attribute__((ext_vector_type(4)));
+
+enum { K_RBF = 0, K_M12 = 1, K_M32 = 2, K_M52 = 3, K_LIN = 4 };
+
+struct Hyp { double noise, mean, os, ls; };
+
+__device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
+__device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
+
+__device__ __forceinline__ Hyp load_hyp(const float* __restrict__ raw) {
+  Hyp h;
+  h.noise = (double)(softplus_f(raw[0]) + 1e-4f);
+  h.mean = (double)raw[1];
+  h.os = (double)softplus_f(raw[2]);
+  h.ls = (double)softplus_f(raw[3]);
+  return h;
+}
+
+// base kernel value from the pair statistic (squared distance, or dot product for linear)
+template <int KID>
+__device__ __forceinline__ double kern_val(double st, double ls) {
+  if (KID == K_LIN) return ls * st;
+  if (KID == K_RBF) return exp(-0.5 * st / (ls * ls));
+  double r = sqrt(fmax(st / (ls * ls), 1e-30));
+  if (KID == K_M12) return exp(-r);
+  if (KID == K_M32) { double s = 1.7320508075688772 * r; return (s + 1.0) * exp(-s); }
+  double s = 2.23606797749979 * r;
+  return (s + 1.0 + (5.0 / 3.0) * r * r) * exp(-s);
+}
+
+// value and d/d(lengthscale) (d/d(variance) for linear)
+template <int KID>
+__device__ __forceinline__ void kern_val_dl(double st, double ls, double& k, double& dk) {
+  if (KID == K_LIN) { k = ls * st; dk = st; return; }
+  if (KID == K_RBF) { k = exp(-0.5 * st / (ls * ls)); dk = k * st / (ls * ls * ls); return; }
+  double r = sqrt(fmax(st / (ls * ls), 1e-30));
+  if (KID == K_M12) { k = exp(-r); dk = k * r / ls; return; }
+  if (KID == K_M32) {
+    double s = 1.7320508075688772 * r, e = exp(-s);
+    k = (s + 1.0) * e; dk = 3.0 * r * r * e / ls; return;
+  }
+  double s = 2.23606797749979 * r, e = exp(-s);
+  k = (s + 1.0 + (5.0 / 3.0) * r * r) * e;
+  dk = (5.0 / 3.0) * r * r * (1.0 + s) * e / ls;
+}
+
+template <int KID>
+__device__ __forceinline__ double pair_stat(const double* __restrict__ a, const double* __restrict__ b, int d) {
+  double s = 0.0;
+  if (KID == K_LIN) {
+    for (int f = 0; f < d; ++f) s = fma(a[f], b[f], s);
+  } else {
+    for (int f = 0; f < d; ++f) { double t = a[f] - b[f]; s = fma(t, t, s); }
+  }
+  return s;
+}
+
+// lower-triangular tile enumeration: t -> (I, J), I >= J
+__device__ __forceinline__ void tri_decode(int t, int& I, int& J) {
+  int i = 0;
+  while ((i + 1) * (i + 2) / 2 <= t) ++i;
+  I = i; J = t - i * (i + 1) / 2;
+}
+
+// XCD-aware work-item remap: blocks b and b+8 share an XCD (speed only); give each
+// XCD a contiguous range of the virtual index so the tiles of one GP share an L2.
+__device__ __forceinline__ int xcd_remap(int bid, int total) {
+  int q = total >> 3, r = total & 7, x = bid & 7, s = bid >> 3;
+  int base = (x < r) ? x * (q + 1) : r * (q + 1) + (x - r) * q;
+  return base + s;
+}
+
+// ---------------------------------------------------------------- K1 gather
+__global__ void k_gather(const double* __restrict__ tin, const double* __restrict__ ttg,
+                         const double* __restrict__ tst, int H, int W, int s, int p,
+                         const int32_t* __restrict__ locs, const int32_t* __restrict__ tidx, int nt,
+                         double* __restrict__ X, double* __restrict__ y, double* __restrict__ Xs) {
+  const int b = blockIdx.y;
+  const int r0 = locs[2 * b], c0 = locs[2 * b + 1];
+  const int n = nt * nt, P = p * s, ms = P - 2, m = ms * ms, Ws = W * s;
+  const int dy[8] = {1, -1, 0, 0, 1, -1, 1, -1};
+  const int dx[8] = {0, 0, 1, -1, 1, -1, -1, 1};
+  const int total = 9 * n + 8 * m;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    if (e < 8 * n) {
+      int q = e >> 3, f = e & 7;
+      int yy = tidx[q / nt], xx = tidx[q % nt];
+      X[(size_t)b * n * 8 + e] = tin[(size_t)(r0 + yy + dy[f]) * W + c0 + xx + dx[f]];
+    } else if (e < 9 * n) {
+      int q = e - 8 * n;
+      int yy = tidx[q / nt], xx = tidx[q % nt];
+      y[(size_t)b * n + q] = ttg[(size_t)(r0 + yy) * W + c0 + xx];
+    } else {
+      int e2 = e - 9 * n;
+      int q = e2 >> 3, f = e2 & 7;
+      int yy = 1 + q / ms, xx = 1 + q % ms;
+      Xs[(size_t)b * m * 8 + e2] = tst[(size_t)(r0 * s + yy + dy[f]) * Ws + c0 * s + xx + dx[f]];
+    }
+  }
+}
+
+// ------------------------------------------------------- initial hypers
+__global__ void k_init_hypers(const double* __restrict__ y, int n, int kid, float raw_noise0,
+                              float raw_ls_rbf, float init_os, float init_ls,
+                              const float* __restrict__ carry, float* __restrict__ raw) {
+  __shared__ double red[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const double* yb = y + (size_t)b * n;
+  double s = 0.0;
+  for (int i = tid; i < n; i += 256) s += (double)(float)yb[i];
+  red[tid] = s; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  const double mean = red[0] / n;
+  __syncthreads();
+  double v = 0.0;
+  for (int i = tid; i < n; i += 256) { double t = (double)(float)yb[i] - mean; v += t * t; }
+  red[tid] = v; __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) { if (tid < o) red[tid] += red[tid + o]; __syncthreads(); }
+  if (tid == 0) {
+    float* r = raw + 4 * b;
+    r[0] = raw_noise0;
+    r[1] = (float)mean;
+    if (kid == K_RBF) {
+      float var = (float)(red[0] / (n - 1));
+      r[2] = var + logf(-expm1f(-var));  // inv_softplus
+      r[3] = raw_ls_rbf;
+    } else if (carry) {
+      r[2] = carry[2]; r[3] = carry[3];
+    } else {
+      r[2] = init_os; r[3] = init_ls;
+    }
+  }
+}
+
+// ---------------------------------------------------------- K2 covariance
+// grid.x = ntri * B (xcd-remapped), 256 threads, dynamic LDS = 2*NB*(d+1) doubles
+template <int KID>
+__global__ void k_build(const double* __restrict__ X, const float* __restrict__ raw,
+                        double* __restrict__ A, int n, int N, int d, int ntri, int total,
+                        double* __restrict__ logdet) {
+  extern __shared__ double sm[];
+  const int v = xcd_remap(blockIdx.x, total);
+  const int b = v / ntri, t = v % ntri;
+  int I, J; tri_decode(t, I, J);
+  const int ldx = d + 1;
+  double* xi = sm; double* xj = sm + NB * ldx;
+  const double* Xb = X + (size_t)b * n * d;
+  for (int e = threadIdx.x; e < NB * d; e += blockDim.x) {
+    int r = e / d, f = e % d;
+    int gi = I * NB + r, gj = J * NB + r;
+    xi[r * ldx + f] = gi < n ? Xb[(size_t)gi * d + f] : 0.0;
+    xj[r * ldx + f] = gj < n ? Xb[(size_t)gj * d + f] : 0.0;
+  }
+  const Hyp h = load_hyp(raw + 4 * b);
+  if (t == 0 && threadIdx.x == 0 && logdet) logdet[b] = 0.0;
+  __syncthreads();
+  double* Ab = A + (size_t)b * N * N;
+  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
+    int i = e / NB, j = e % NB;
+    int gi = I * NB + i, gj = J * NB + j;
+    double val;
+    if (gi < n && gj < n) {
+      double st = pair_stat<KID>(xi + i * ldx, xj + j * ldx, d);
+      val = h.os * kern_val<KID>(st, h.ls);
+      if (gi == gj) val += h.noise;
+    } else {
+      val = (gi == gj) ? 1.0 : 0.0;
+    }
+    Ab[(size_t)gi * N + gj] = val;
+  }
+}
+
+// ------------------------------------------------------------ pivot block
+// One workgroup (448 threads) per GP.  Thread t owns column l = t % NB and rows
+// rg + 4c (rg = t / NB, c = 0..27) of the NBxNB pivot block in registers and runs
+// the unblocked symmetric sweep with one barrier per pivot.
+__global__ void __launch_bounds__(MM_THREADS)
+k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Pbuf,
+        double* __restrict__ logdet, int32_t* __restrict__ flags) {
+  __shared__ double colbuf[2][NB];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int l = tid % NB, rg = tid / NB;
+  double* Akk = A + (size_t)b * N * N + (size_t)(k * NB) * N + k * NB;
+  double a[28];
+#pragma unroll
+  for (int c = 0; c < 28; ++c) a[c] = Akk[(size_t)(rg + 4 * c) * N + l];
+  double ld = 0.0;
+  int bad = 0;
+  if (l == 0) {
+#pragma unroll
+    for (int c = 0; c < 28; ++c) colbuf[0][rg + 4 * c] = a[c];
+  }
+  __syncthreads();
+  for (int j = 0; j < NB; ++j) {
+    const double* cb = colbuf[j & 1];
+    const double pv = cb[j];
+    if (!(pv > 0.0)) bad = 1;
+    ld += log(pv);
+    const double inv = 1.0 / pv;
+    const double cl = cb[l];
+    const double clinv = cl * inv;
+    const bool lj = (l == j);
+#pragma unroll
+    for (int c = 0; c < 28; ++c) {
+      const int i = rg + 4 * c;
+      const double ci = cb[i];
+      double upd = lj ? ci * inv : fma(-ci, clinv, a[c]);
+      double rowj = lj ? -inv : clinv;
+      a[c] = (i == j) ? rowj : upd;
+    }
+    if (l == j + 1) {  // publish next pivot column
+#pragma unroll
+      for (int c = 0; c < 28; ++c) colbuf[(j + 1) & 1][rg + 4 * c] = a[c];
+    }
+    __syncthreads();
+  }
+  double* Pb = Pbuf + (size_t)b * NB * NB;
+#pragma unroll
+  for (int c = 0; c < 28; ++c) {
+    const int i = rg + 4 * c;
+    Akk[(size_t)i * N + l] = a[c];
+    Pb[i * NB + l] = -a[c];
+  }
+  if (tid == 0) {
+    logdet[b] += ld;
+    if (bad) flags[b] = 1;
+  }
+}
+
+// ------------------------------------------------- shared MFMA tile product
+// acc[t] (16 rows of this wave x 16 cols of tile t) += sum_kk Aop[kk][m] * Bop[kk][nn]
+// over kk in [0, NB).  Aop/Bop are "k-major" sources: element (kk, c) at
+// ptr[kk*ld + c]; if TRANS_B, Bop is row-major instead: element (kk, c) at ptr[c*ld + kk].
+// Staged through LDS in chunks of KC with register prefetch of the next chunk.
+struct Stage { double a[4]; double b[4]; };
+
+template <bool TRANS_B>
+__device__ __forceinline__ void stage_load(Stage& s, const double* __restrict__ Aop, int lda,
+                                           const double* __restrict__ Bop, int ldb, int chunk, int tid) {
+  const int idx = tid * 4;
+  {
+    const int kk = idx / NB, c = idx % NB;
+    const double* p = Aop + (size_t)(chunk * KC + kk) * lda + c;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s.a[u] = p[u];
+  }
+  if (!TRANS_B) {
+    const int kk = idx / NB, c = idx % NB;
+    const double* p = Bop + (size_t)(chunk * KC + kk) * ldb + c;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s.b[u] = p[u];
+  } else {
+    const int r = idx / KC, kq = idx % KC;
+    const double* p = Bop + (size_t)r * ldb + chunk * KC + kq;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s.b[u] = p[u];
+  }
+}
+
+template <bool TRANS_B>
+__device__ __forceinline__ void stage_store(const Stage& s, double* __restrict__ As, double* __restrict__ Bs, int tid) {
+  const int idx = tid * 4;
+  {
+    const int kk = idx / NB, c = idx % NB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) As[kk * LDS_LD + c + u] = s.a[u];
+  }
+  if (!TRANS_B) {
+    const int kk = idx / NB, c = idx % NB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Bs[kk * LDS_LD + c + u] = s.b[u];
+  } else {
+    const int r = idx / KC, kq = idx % KC;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Bs[(kq + u) * LDS_LD + r] = s.b[u];
+  }
+}
+
+__device__ __forceinline__ void chunk_mfma(const double* __restrict__ As, const double* __restrict__ Bs,
+                                           v4d acc[NBT], int wave, int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < KC / 4; ++ks) {
+    const int row = (ks * 4 + lk) * LDS_LD;
+    const double av = As[row + 16 * wave + lr];
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) {
+      const double bv = Bs[row + 16 * t + lr];
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ panel
+// grid.x = (nblk-1) * B.  For row block i != k:
+//   T = A_ik (stored as block (i,k) when i > k, as block (k,i) transposed when i < k)
+//   D[k'][r] = sum_kk P[k'][kk] T[r][kk]   (= (A_ik P)^T)
+//   Wo[kk][i0+r] = T[r][kk] ; Wn[k'][i0+r] = -D ; A_ik <- D^T
+__global__ void __launch_bounds__(MM_THREADS)
+k_panel(double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Pbuf,
+        double* __restrict__ Wn, double* __restrict__ Wo, int total) {
+  __shared__ double lds[2 * KC * LDS_LD];
+  double* As = lds; double* Bs = lds + KC * LDS_LD;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int v = xcd_remap(blockIdx.x, total);
+  const int b = v / (nblk - 1);
+  int i = v % (nblk - 1); if (i >= k) ++i;
+  double* Ab = A + (size_t)b * N * N;
+  const double* P = Pbuf + (size_t)b * NB * NB;
+  double* Wnb = Wn + (size_t)b * NB * N;
+  double* Wob = Wo + (size_t)b * NB * N;
+  const int i0 = i * NB, k0 = k * NB;
+  const bool below = i > k;
+  // T source: below: row-major [r][kk] at A[(i0+r)*N + k0+kk]; above: k-major [kk][r] at A[(k0+kk)*N + i0+r]
+  const double* Tsrc = below ? Ab + (size_t)i0 * N + k0 : Ab + (size_t)k0 * N + i0;
+  v4d acc[NBT];
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  Stage st;
+  if (below) stage_load<true>(st, P, NB, Tsrc, N, 0, tid); else stage_load<false>(st, P, NB, Tsrc, N, 0, tid);
+  for (int ch = 0; ch < NB / KC; ++ch) {
+    __syncthreads();
+    if (below) stage_store<true>(st, As, Bs, tid); else stage_store<false>(st, As, Bs, tid);
+    __syncthreads();
+    if (ch + 1 < NB / KC) {
+      if (below) stage_load<true>(st, P, NB, Tsrc, N, ch + 1, tid); else stage_load<false>(st, P, NB, Tsrc, N, ch + 1, tid);
+    }
+    {  // old panel out: Wo[ch*KC + kk][i0 + c..c+3] = Bs[kk][c..]
+      const int idx = tid * 4, kk = idx / NB, c = idx % NB;
+      double* dst = Wob + (size_t)(ch * KC + kk) * N + i0 + c;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) dst[u] = Bs[kk * LDS_LD + c + u];
+    }
+    chunk_mfma(As, Bs, acc, wave, lane);
+  }
+  // D rows k' = 16*wave + (lane>>4) + 4*rr, cols r = 16*t + (lane&15)
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int kp = 16 * wave + lk + 4 * rr;
+      Wnb[(size_t)kp * N + i0 + 16 * t + lr] = -acc[t][rr];
+      if (!below) Ab[(size_t)(k0 + kp) * N + i0 + 16 * t + lr] = acc[t][rr];
+    }
+  }
+  if (below) {
+    __syncthreads();  // staging buffers are free now; per-wave 16x17 transpose scratch
+    double* tr = lds + wave * (16 * 17);
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) tr[(lk + 4 * rr) * 17 + lr] = acc[t][rr];  // [k' local][r local]
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) {
+        const int rl = lk + 4 * rr;  // r local
+        Ab[(size_t)(i0 + 16 * t + rl) * N + k0 + 16 * wave + lr] = tr[lr * 17 + rl];
+      }
+      __builtin_amdgcn_wave_barrier();
+    }
+  }
+}
+
+// ----------------------------------------------------------------- update
+// grid.x = ntri(nblk-1) * B.  A_IJ += Wn_I^T-product: A[I0+m][J0+nn] += sum_kk Wn[kk][I0+m] Wo[kk][J0+nn]
+__global__ void __launch_bounds__(MM_THREADS)
+k_update(double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Wn,
+         const double* __restrict__ Wo, int ntri1, int total) {
+  __shared__ double lds[2 * KC * LDS_LD];
+  double* As = lds; double* Bs = lds + KC * LDS_LD;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int v = xcd_remap(blockIdx.x, total);
+  const int b = v / ntri1, t0 = v % ntri1;
+  int I, J; tri_decode(t0, I, J);
+  if (I >= k) ++I;
+  if (J >= k) ++J;
+  double* Ab = A + (size_t)b * N * N;
+  const double* Aop = Wn + (size_t)b * NB * N + I * NB;
+  const double* Bop = Wo + (size_t)b * NB * N + J * NB;
+  const int lr = lane & 15, lk = lane >> 4;
+  double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + J * NB + lr;
+  Stage st;
+  stage_load<false>(st, Aop, N, Bop, N, 0, tid);
+  v4d acc[NBT];
+#pragma unroll
+  for (int t = 0; t < NBT; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) acc[t][rr] = Ct[(size_t)(4 * rr) * N + 16 * t];
+  for (int ch = 0; ch < NB / KC; ++ch) {
+    __syncthreads();
+    stage_store<false>(st, As, Bs, tid);
+    __syncthreads();
+    if (ch + 1 < NB / KC) stage_load<false>(st, Aop, N, Bop, N, ch + 1, tid);
+    chunk_mfma(As, Bs, acc, wave, lane);
+  }
+#pragma unroll
+  for (int t = 0; t < NBT; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+}
+
+// ------------------------------------------------------------------ grad1
+// grid (nblk, B), 448 threads.  With A = -Kinv (lower block-triangle):
+//   alpha_i = sum_j Kinv_ij r_j,  r = y - mean (0 for padded rows)
+// stats1[b][I][0..3] = { sum_i Kinv_ii, sum alpha^2, sum alpha r, sum alpha }  over rows of block I, i < n
+__global__ void __launch_bounds__(MM_THREADS)
+k_grad1(const double* __restrict__ A, int N, int n, int nblk, const double* __restrict__ y,
+        const float* __restrict__ raw, double* __restrict__ alpha, double* __restrict__ stats1) {
+  extern __shared__ double sm[];  // r[N] | part[4][NB] | rowacc[NB] | red[8*4]
+  double* r = sm; double* part = sm + N; double* rowacc = part + 4 * NB; double* red = rowacc + NB;
+  const int I = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const double mean = (double)raw[4 * b + 1];
+  const double* yb = y + (size_t)b * n;
+  for (int i = tid; i < N; i += MM_THREADS) r[i] = i < n ? yb[i] - mean : 0.0;
+  __syncthreads();
+  const double* Ab = A + (size_t)b * N * N;
+  const int I0 = I * NB;
+  // part A: rows of block I, columns [0, I0+NB)
+  const int ncols = I0 + NB;
+  for (int q = 0; q < 16; ++q) {
+    const int row = 16 * wave + q;
+    const double* ar = Ab + (size_t)(I0 + row) * N;
+    double s = 0.0;
+    for (int j = lane; j < ncols; j += 64) s = fma(ar[j], r[j], s);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) rowacc[row] = s;
+  }
+  // part B: columns of block I in the blocks below
+  {
+    const int c = tid % NB, g = tid / NB;
+    double s = 0.0;
+    for (int ip = I0 + NB + g; ip < N; ip += 4) s = fma(Ab[(size_t)ip * N + I0 + c], r[ip], s);
+    part[g * NB + c] = s;
+  }
+  __syncthreads();
+  double st[4] = {0.0, 0.0, 0.0, 0.0};
+  if (tid < NB) {
+    const int gi = I0 + tid;
+    double s = rowacc[tid] + ((part[tid] + part[NB + tid]) + (part[2 * NB + tid] + part[3 * NB + tid]));
+    double al = gi < n ? -s : 0.0;
+    alpha[(size_t)b * N + gi] = al;
+    if (gi < n) {
+      st[0] = -Ab[(size_t)gi * N + gi];
+      st[1] = al * al; st[2] = al * r[gi]; st[3] = al;
+    }
+  }
+  if (tid < 128) {  // waves 0,1 reduce
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      double s = st[u];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+      if (lane == 0) red[wave * 4 + u] = s;
+    }
+  }
+  __syncthreads();
+  if (tid < 4) stats1[((size_t)b * nblk + I) * 4 + tid] = red[tid] + red[4 + tid];
+}
+
+// ------------------------------------------------------------------ grad2
+// grid.x = ntri*B, 256 threads, dynamic LDS = 2*NB*(d+1) + 2*NB doubles.
+// stats2[b][t][0..1] = sum over tile of (Kinv_ij - a_i a_j) * {k_ij, dk_ij/dl}, off-diagonal tiles x2
+template <int KID>
+__global__ void k_grad2(const double* __restrict__ A, const double* __restrict__ X,
+                        const float* __restrict__ raw, const double* __restrict__ alpha,
+                        int n, int N, int d, int ntri, int total, double* __restrict__ stats2) {
+  extern __shared__ double sm[];
+  const int v = xcd_remap(blockIdx.x, total);
+  const int b = v / ntri, t = v % ntri;
+  int I, J; tri_decode(t, I, J);
+  const int ldx = d + 1;
+  double* xi = sm; double* xj = sm + NB * ldx; double* ai = xj + NB * ldx; double* aj = ai + NB;
+  __shared__ double red[2][4];
+  const double* Xb = X + (size_t)b * n * d;
+  for (int e = threadIdx.x; e < NB * d; e += blockDim.x) {
+    int r = e / d, f = e % d;
+    int gi = I * NB + r, gj = J * NB + r;
+    xi[r * ldx + f] = gi < n ? Xb[(size_t)gi * d + f] : 0.0;
+    xj[r * ldx + f] = gj < n ? Xb[(size_t)gj * d + f] : 0.0;
+  }
+  for (int e = threadIdx.x; e < NB; e += blockDim.x) {
+    ai[e] = alpha[(size_t)b * N + I * NB + e];
+    aj[e] = alpha[(size_t)b * N + J * NB + e];
+  }
+  const Hyp h = load_hyp(raw + 4 * b);
+  __syncthreads();
+  const double* Ab = A + (size_t)b * N * N;
+  double s0 = 0.0, s1 = 0.0;
+  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
+    int i = e / NB, j = e % NB;
+    int gi = I * NB + i, gj = J * NB + j;
+    if (gi < n && gj < n) {
+      double w = -Ab[(size_t)gi * N + gj] - ai[i] * aj[j];
+      double st = pair_stat<KID>(xi + i * ldx, xj + j * ldx, d);
+      double kv, dk;
+      kern_val_dl<KID>(st, h.ls, kv, dk);
+      s0 = fma(w, kv, s0);
+      s1 = fma(w, dk, s1);
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+  if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+  __syncthreads();
+  if (threadIdx.x < 2) {
+    double s = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
+    if (I != J) s *= 2.0;
+    stats2[((size_t)b * ntri + t) * 2 + threadIdx.x] = s;
+  }
+}
+
+// ------------------------------------------------------------- loss/grad/Adam
+// One thread per GP.  do_step: torch.optim.Adam single-tensor update in float32.
+__global__ void k_adam(float* __restrict__ raw, float* __restrict__ m1, float* __restrict__ m2,
+                       const double* __restrict__ stats1, const double* __restrict__ stats2,
+                       const double* __restrict__ logdet, int B, int n, int nblk, int ntri,
+                       double* __restrict__ loss_out, float* __restrict__ grad_out, int do_step,
+                       float step_size, float bc2_sqrt, float one_minus_b1, float b2,
+                       float one_minus_b2, float eps) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  double tr = 0.0, aa = 0.0, ar = 0.0, sa = 0.0;
+  for (int I = 0; I < nblk; ++I) {
+    const double* s = stats1 + ((size_t)b * nblk + I) * 4;
+    tr += s[0]; aa += s[1]; ar += s[2]; sa += s[3];
+  }
+  double sk = 0.0, sd = 0.0;
+  for (int t = 0; t < ntri; ++t) { sk += stats2[((size_t)b * ntri + t) * 2]; sd += stats2[((size_t)b * ntri + t) * 2 + 1]; }
+  float* r = raw + 4 * b;
+  const double os = (double)softplus_f(r[2]);
+  const double dn = (double)n;
+  const double loss = 0.5 * (ar + logdet[b] + dn * 1.8378770664093453) / dn;
+  if (loss_out) loss_out[b] = loss;
+  float g[4];
+  g[0] = (float)(0.5 * (tr - aa) / dn) * sigmoid_f(r[0]);
+  g[1] = (float)(-sa / dn);
+  g[2] = (float)(0.5 * sk / dn) * sigmoid_f(r[2]);
+  g[3] = (float)(0.5 * os * sd / dn) * sigmoid_f(r[3]);
+  if (grad_out) { for (int u = 0; u < 4; ++u) grad_out[4 * b + u] = g[u]; }
+  if (do_step) {
+    for (int u = 0; u < 4; ++u) {
+      float gu = g[u];
+      float ea = m1[4 * b + u];
+      ea = ea + one_minus_b1 * (gu - ea);               // lerp_
+      float es = m2[4 * b + u] * b2 + one_minus_b2 * gu * gu;  // mul_().addcmul_()
+      m1[4 * b + u] = ea; m2[4 * b + u] = es;
+      float denom = sqrtf(es) / bc2_sqrt + eps;
+      r[u] = r[u] - step_size * (ea / denom);
+    }
+  }
+}
+
+// ---------------------------------------------------------------- K5 predict
+// grid (ceil(m / (256*TP)), B), 256 threads, dynamic LDS = n*9 doubles.  d == 8.
+#define PRED_TP 4
+template <int KID>
+__global__ void __launch_bounds__(256)
+k_predict(const double* __restrict__ X, const double* __restrict__ Xs, const double* __restrict__ alpha,
+          const float* __restrict__ raw, int n, int N, int m, double* __restrict__ out) {
+  extern __shared__ double sm[];
+  double* xs = sm; double* al = sm + (size_t)n * 8;
+  const int b = blockIdx.y, tid = threadIdx.x;
+  const double* Xb = X + (size_t)b * n * 8;
+  for (int e = tid; e < n * 8; e += 256) xs[e] = Xb[e];
+  for (int e = tid; e < n; e += 256) al[e] = alpha[(size_t)b * N + e];
+  const Hyp h = load_hyp(raw + 4 * b);
+  __syncthreads();
+  const int base = blockIdx.x * 256 * PRED_TP;
+  double q[PRED_TP][8];
+  double acc[PRED_TP];
+  const double* Xsb = Xs + (size_t)b * m * 8;
+#pragma unroll
+  for (int u = 0; u < PRED_TP; ++u) {
+    int t = base + u * 256 + tid;
+    acc[u] = 0.0;
+#pragma unroll
+    for (int f = 0; f < 8; ++f) q[u][f] = t < m ? Xsb[(size_t)t * 8 + f] : 0.0;
+  }
+  for (int i = 0; i < n; ++i) {
+    double xr[8];
+#pragma unroll
+    for (int f = 0; f < 8; ++f) xr[f] = xs[i * 8 + f];
+    const double a = al[i];
+#pragma unroll
+    for (int u = 0; u < PRED_TP; ++u) {
+      double st = 0.0;
+#pragma unroll
+      for (int f = 0; f < 8; ++f) {
+        if (KID == K_LIN) st = fma(q[u][f], xr[f], st);
+        else { double dlt = q[u][f] - xr[f]; st = fma(dlt, dlt, st); }
+      }
+      acc[u] = fma(kern_val<KID>(st, h.ls), a, acc[u]);
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < PRED_TP; ++u) {
+    int t = base + u * 256 + tid;
+    if (t < m) out[(size_t)b * m + t] = h.mean + h.os * acc[u];
+  }
+}
+
+// ---------------------------------------------------------------- K6 combine
+// one thread per HR pixel; contributions are added in patch order (row-major over rows x cols)
+__global__ void k_combine(const double* __restrict__ pred, const double* __restrict__ tst, int H, int W,
+                          int s, int p, const int32_t* __restrict__ rows, int nr,
+                          const int32_t* __restrict__ cols, int nc, int mode, int clip,
+                          double* __restrict__ out) {
+  const int Hs = H * s, Ws = W * s, P = p * s, ms = P - 2;
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)Hs * Ws) return;
+  const int R = (int)(idx / Ws), C = (int)(idx % Ws);
+  double acc = 0.0, wsum = 0.0;
+  const bool full = (tst == nullptr);  // pred holds whole [P][P] patches, rim included
+  const double pix = full ? 0.0 : tst[idx];
+  const size_t m = (size_t)ms * ms;
+  for (int ir = 0; ir < nr; ++ir) {
+    const int x = rows[ir] * s;
+    const int i = R - x;
+    if (i < 0 || i >= P) continue;
+    const int xs_ = (x == 0) ? 0 : 1;
+    const int xe = (x + P == Hs) ? P : P - 1;
+    if (i < xs_ || i >= xe) continue;
+    for (int ic = 0; ic < nc; ++ic) {
+      const int y = cols[ic] * s;
+      const int j = C - y;
+      if (j < 0 || j >= P) continue;
+      const int ys_ = (y == 0) ? 0 : 1;
+      const int ye = (y + P == Ws) ? P : P - 1;
+      if (j < ys_ || j >= ye) continue;
+      double v;
+      if (full)
+        v = pred[(size_t)(ir * nc + ic) * P * P + (size_t)i * P + j];
+      else if (i >= 1 && i <= P - 2 && j >= 1 && j <= P - 2)
+        v = pred[(size_t)(ir * nc + ic) * m + (size_t)(i - 1) * ms + (j - 1)];
+      else
+        v = pix;
+      if (mode == 0) {
+        acc = __dadd_rn(acc, v);
+        wsum = __dadd_rn(wsum, 1.0);
+      } else {
+        double vw = 1.0 - fabs(0.5 - (double)i / (double)P);
+        double hw = 1.0 - fabs(0.5 - (double)j / (double)P);
+        double w = __dmul_rn(vw, hw);
+        acc = __dadd_rn(acc, __dmul_rn(v, w));
+        wsum = __dadd_rn(wsum, w);
+      }
+    }
+  }
+  double r = acc / wsum;
+  out[idx] = clip ? fmin(fmax(r, 0.0), 1.0) : r;
+}
+
+// ---------------------------------------------------------------- K7 AGPR
+// w[f] = os * var * sum_i X[i][f] alpha[i]    (one block, d <= 64 threads active)
+__global__ void k_agpr_weights(const double* __restrict__ X, const double* __restrict__ alpha,
+                               const float* __restrict__ raw, int n, int d, double* __restrict__ w) {
+  const int f = threadIdx.x;
+  if (f >= d) return;
+  const Hyp h = load_hyp(raw);
+  double s = 0.0;
+  for (int i = 0; i < n; ++i) s = fma(X[(size_t)i * d + f], alpha[i], s);
+  w[f] = h.os * h.ls * s;
+}
+
+__global__ void k_agpr_filter(const double* __restrict__ img, int Hs, int Ws, int L,
+                              const double* __restrict__ w, const float* __restrict__ raw,
+                              double* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)Hs * Ws) return;
+  const int pad = L / 2;
+  const int i = (int)(idx / Ws), j = (int)(idx % Ws);
+  if (i < pad || i >= Hs - pad || j < pad || j >= Ws - pad) { out[idx] = img[idx]; return; }
+  double s = 0.0;
+  for (int a = 0; a < L; ++a)
+    for (int c = 0; c < L; ++c)
+      s = fma((double)(float)img[(size_t)(i - pad + a) * Ws + (j - pad + c)], w[a * L + c], s);
+  out[idx] = (double)raw[1] + s;
+}
+
+// ---------------------------------------------------------------- self-test
+__global__ void k_selftest_mfma(const double* __restrict__ A, const double* __restrict__ Bm, double* __restrict__ D) {
+  const int lane = threadIdx.x;
+  const double a = A[(lane & 15) * 4 + (lane >> 4)];   // A[i][k], 16x4 row-major
+  const double b = Bm[(lane >> 4) * 16 + (lane & 15)];  // B[k][j], 4x16 row-major
+  v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+  acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
+  for (int rr = 0; rr < 4; ++rr) D[((lane >> 4) + 4 * rr) * 16 + (lane & 15)] = acc[rr];
+}

@@ -1,0 +1,166 @@
+"""Thin torch-tensor wrappers over the C ABI (include/gpsr.h).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; all
+arithmetic on the path happens in libgpsr.so.  Every function requires CUDA
+(ROCm) tensors and raises otherwise -- there is no CPU path.
+"""
+import numpy as np
+import torch
+
+from . import _lib
+
+RBF, MATERN12, MATERN32, MATERN52, LINEAR = 0, 1, 2, 3, 4
+AVERAGE, BILINEAR = 0, 1
+BLOCK = 112
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _p(t, dtype=None):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise _lib.GpsrError("gpsr ops need device tensors (no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise _lib.GpsrError(f"expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise _lib.GpsrError("tensor must be contiguous")
+    return t.data_ptr()
+
+
+def padded_n(n):
+    return ((n + BLOCK - 1) // BLOCK) * BLOCK
+
+
+def gather(train_in, train_tgt, test_in, s, p, locs, tidx):
+    """-> X [B,n,8], y [B,n], Xs [B,m,8]   (gpsr_gather)."""
+    lib = _lib.load()
+    H, W = train_in.shape
+    B, nt = locs.shape[0], tidx.shape[0]
+    n, m = nt * nt, (p * s - 2) ** 2
+    dev = train_in.device
+    X = torch.empty((B, n, 8), dtype=torch.float64, device=dev)
+    y = torch.empty((B, n), dtype=torch.float64, device=dev)
+    Xs = torch.empty((B, m, 8), dtype=torch.float64, device=dev)
+    _lib.check(lib.gpsr_gather(_p(train_in, torch.float64), _p(train_tgt, torch.float64),
+                               _p(test_in, torch.float64), H, W, s, p, _p(locs, torch.int32), B,
+                               _p(tidx, torch.int32), nt, _p(X), _p(y), _p(Xs), _stream()), "gpsr_gather")
+    return X, y, Xs
+
+
+def init_hypers(y, kernel_id, init_raw_os=0.0, init_raw_ls=0.0, carry=None):
+    lib = _lib.load()
+    B, n = y.shape
+    raw = torch.empty((B, 4), dtype=torch.float32, device=y.device)
+    _lib.check(lib.gpsr_init_hypers(_p(y, torch.float64), B, n, kernel_id, float(init_raw_os), float(init_raw_ls),
+                                    _p(carry, torch.float32), _p(raw), _stream()), "gpsr_init_hypers")
+    return raw
+
+
+def covariance(X, kernel_id, raw):
+    lib = _lib.load()
+    B, n, d = X.shape
+    N = padded_n(n)
+    K = torch.zeros((B, N, N), dtype=torch.float64, device=X.device)
+    _lib.check(lib.gpsr_covariance(_p(X, torch.float64), B, n, d, kernel_id, _p(raw, torch.float32), _p(K),
+                                   _stream()), "gpsr_covariance")
+    return K
+
+
+def invert_(A):
+    """In-place: A[b] <- -inv(A[b]) (lower block-triangle).  Returns logdet, flags."""
+    lib = _lib.load()
+    B, N, _ = A.shape
+    nbytes = lib.gpsr_invert_workspace_bytes(B, N)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
+    logdet = torch.empty(B, dtype=torch.float64, device=A.device)
+    flags = torch.empty(B, dtype=torch.int32, device=A.device)
+    _lib.check(lib.gpsr_invert(_p(A, torch.float64), B, N, _p(logdet), _p(flags), _p(ws), nbytes, _stream()),
+               "gpsr_invert")
+    return logdet, flags
+
+
+def fit_workspace(B, n, d, device):
+    lib = _lib.load()
+    nbytes = lib.gpsr_fit_workspace_bytes(B, n, d)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def fit(X, y, kernel_id, raw, iters=50, lr=0.1, workspace=None, want_loss=False):
+    """Adam fit in place on raw [B,4]; returns alpha [B,N], flags [B] (, loss [B])."""
+    lib = _lib.load()
+    B, n, d = X.shape
+    N = padded_n(n)
+    if workspace is None:
+        workspace = fit_workspace(B, n, d, X.device)
+    alpha = torch.empty((B, N), dtype=torch.float64, device=X.device)
+    flags = torch.empty(B, dtype=torch.int32, device=X.device)
+    loss = torch.empty(B, dtype=torch.float64, device=X.device) if want_loss else None
+    _lib.check(lib.gpsr_fit(_p(X, torch.float64), _p(y, torch.float64), B, n, d, kernel_id, _p(raw, torch.float32),
+                            iters, float(lr), _p(alpha), _p(loss), _p(flags), _p(workspace), workspace.numel(),
+                            _stream()), "gpsr_fit")
+    return (alpha, flags, loss) if want_loss else (alpha, flags)
+
+
+def loss_grad(X, y, kernel_id, raw, workspace=None):
+    lib = _lib.load()
+    B, n, d = X.shape
+    if workspace is None:
+        workspace = fit_workspace(B, n, d, X.device)
+    loss = torch.empty(B, dtype=torch.float64, device=X.device)
+    grad = torch.empty((B, 4), dtype=torch.float32, device=X.device)
+    flags = torch.empty(B, dtype=torch.int32, device=X.device)
+    _lib.check(lib.gpsr_loss_grad(_p(X, torch.float64), _p(y, torch.float64), B, n, d, kernel_id,
+                                  _p(raw, torch.float32), _p(loss), _p(grad), _p(flags), _p(workspace),
+                                  workspace.numel(), _stream()), "gpsr_loss_grad")
+    return loss, grad, flags
+
+
+def predict(X, Xs, alpha, raw, kernel_id):
+    lib = _lib.load()
+    B, n, d = X.shape
+    if d != 8:
+        raise _lib.GpsrError("gpsr_predict needs d == 8")
+    m = Xs.shape[1]
+    out = torch.empty((B, m), dtype=torch.float64, device=X.device)
+    _lib.check(lib.gpsr_predict(_p(X, torch.float64), _p(Xs, torch.float64), _p(alpha, torch.float64),
+                                _p(raw, torch.float32), B, n, m, kernel_id, _p(out), _stream()), "gpsr_predict")
+    return out
+
+
+def combine(pred, test_in, H, W, s, p, rows, cols, mode=AVERAGE, clip=True):
+    """test_in=None: pred holds whole [B,P,P] patches (PatchHandler.combine_patches)."""
+    lib = _lib.load()
+    out = torch.empty((H * s, W * s), dtype=torch.float64, device=pred.device)
+    _lib.check(lib.gpsr_combine(_p(pred, torch.float64), _p(test_in, torch.float64), H, W, s, p,
+                                _p(rows, torch.int32), rows.numel(), _p(cols, torch.int32), cols.numel(), mode,
+                                int(clip), _p(out), _stream()), "gpsr_combine")
+    return out
+
+
+def agpr_weights(X, alpha, raw):
+    lib = _lib.load()
+    n, d = X.shape
+    w = torch.empty(d, dtype=torch.float64, device=X.device)
+    _lib.check(lib.gpsr_agpr_weights(_p(X, torch.float64), _p(alpha, torch.float64), _p(raw, torch.float32), n, d,
+                                     _p(w), _stream()), "gpsr_agpr_weights")
+    return w
+
+
+def agpr_filter(img, L, w, raw):
+    lib = _lib.load()
+    Hs, Ws = img.shape
+    out = torch.empty_like(img)
+    _lib.check(lib.gpsr_agpr_filter(_p(img, torch.float64), Hs, Ws, L, _p(w, torch.float64), _p(raw, torch.float32),
+                                    _p(out), _stream()), "gpsr_agpr_filter")
+    return out
+
+
+def selftest_mfma(A, Bm):
+    lib = _lib.load()
+    D = torch.empty((16, 16), dtype=torch.float64, device=A.device)
+    _lib.check(lib.gpsr_selftest_mfma(_p(A, torch.float64), _p(Bm, torch.float64), _p(D), _stream()),
+               "gpsr_selftest_mfma")
+    return D

@@ -1,0 +1,237 @@
+"""GPU parity tests, kernel by kernel, through the C ABI (libgpsr.so) against the
+CPU oracle.  Bars: bit-exact for the index/copy kernels (gather, combine);
+float64 tolerances written at each assert for the numerical kernels."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import gp as ogp
+from oracle import patches as opatch
+
+
+def dev():
+    assert torch.cuda.is_available(), "these tests need the MI355X"
+    return torch.device("cuda:0")
+
+
+def to_dev(a, dtype=None):
+    t = torch.as_tensor(np.ascontiguousarray(a))
+    if dtype is not None:
+        t = t.to(dtype)
+    return t.to(dev())
+
+
+def natural_image(H, W, seed):
+    """Smooth + edges + noise, values k/255 (like a uint8 image / 255)."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    img = gaussian_filter(rng.random((H, W)), 3.0)
+    img = (img - img.min()) / (img.max() - img.min()) * 219 + 16
+    img += rng.normal(0, 2, (H, W))
+    for _ in range(4):
+        a, b, c = rng.normal(size=3)
+        yy, xx = np.mgrid[0:H, 0:W]
+        img += 25 * ((a * (yy - H / 2) + b * (xx - W / 2) + 5 * c) > 0)
+    return np.clip(np.rint(img), 0, 255) / 255.0
+
+
+def test_mfma_lane_maps():
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(0)
+    A = rng.integers(-8, 9, (16, 4)).astype(np.float64)
+    B = rng.integers(-8, 9, (4, 16)).astype(np.float64)  # asymmetric on purpose
+    D = ops.selftest_mfma(to_dev(A), to_dev(B)).cpu().numpy()
+    assert np.array_equal(D, A @ B)
+
+
+@pytest.mark.parametrize("H,W,p,s", [(47, 53, 20, 2), (61, 70, 30, 3), (52, 36, 20, 2)])
+def test_gather_bit_exact(H, W, p, s):
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(H)
+    a, b, c = rng.random((H, W)), rng.random((H, W)), rng.random((H * s, W * s))
+    locs = opatch.patch_locations((H, W), p)
+    tidx = np.arange(1, p - 1, dtype=np.int32)
+    X, y, Xs = ops.gather(to_dev(a), to_dev(b), to_dev(c), s, p, to_dev(np.array(locs, dtype=np.int32)), to_dev(tidx))
+    for k, loc in enumerate(locs):
+        assert np.array_equal(X[k].cpu().numpy(), opatch.features(opatch.extract(a, loc, p, 1)))
+        assert np.array_equal(y[k].cpu().numpy(), opatch.targets(opatch.extract(b, loc, p, 1)))
+        assert np.array_equal(Xs[k].cpu().numpy(), opatch.features(opatch.extract(c, loc, p, s)))
+
+
+def test_gather_grid_training_points():
+    from super_resolution_amd import ops
+    H, W, p, s = 45, 50, 20, 2
+    rng = np.random.default_rng(5)
+    a, b, c = rng.random((H, W)), rng.random((H, W)), rng.random((H * s, W * s))
+    locs = opatch.patch_locations((H, W), p)
+    idx = opatch.grid_training_indices(p)
+    X, y, _ = ops.gather(to_dev(a), to_dev(b), to_dev(c), s, p, to_dev(np.array(locs, dtype=np.int32)),
+                         to_dev(np.array(idx, dtype=np.int32)))
+    for k, loc in enumerate(locs):
+        assert np.array_equal(X[k].cpu().numpy(), opatch.features_at(opatch.extract(a, loc, p, 1), idx))
+        assert np.array_equal(y[k].cpu().numpy(), opatch.targets_at(opatch.extract(b, loc, p, 1), idx))
+
+
+@pytest.mark.parametrize("tag", ["s2", "s3", "s2dup"])
+@pytest.mark.parametrize("mode", [0, 1])
+def test_combine_bit_exact_vs_reference_golden(golden_dir, tag, mode):
+    """Golden = output of the reference's own PatchHandler.combine_patches."""
+    from super_resolution_amd import ops
+    from super_resolution_amd.image_patches import grid_of
+    d = np.load(f"{golden_dir}/patches_iter_combine.npz")
+    H, W, p, s = [int(v) for v in d[tag + "_meta"]]
+    up = d[tag + "_up"]
+    pred = np.ascontiguousarray(up[:, 1:-1, 1:-1].reshape(up.shape[0], -1))
+    rows, cols = grid_of((H, W), p, 0.9)
+    out = ops.combine(to_dev(pred), to_dev(d[tag + "_c"]), H, W, s, p, to_dev(rows), to_dev(cols), mode)
+    want = np.clip(d[tag + ("_avg" if mode == 0 else "_bil")], 0, 1)
+    assert np.array_equal(out.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("kid", [0, 1, 2, 3])
+@pytest.mark.parametrize("exact_hypers", [True, False])
+def test_covariance(kid, exact_hypers):
+    """exact_hypers: raw > 20 so softplus(raw) == raw with no float32 transcendental
+    in the way -> the float64 kernel arithmetic itself is held to 1e-13 (relative).
+    Otherwise the float32 softplus of GPU (ocml) and CPU (torch) may differ by an
+    ulp of float32, so the bar is 5e-7 relative."""
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(kid)
+    B, n = 3, 324
+    X = rng.random((B, n, 8)) * (30.0 if exact_hypers else 1.0)
+    raw = rng.normal(0, 1, (B, 4)).astype(np.float32)
+    if exact_hypers:
+        raw = (21.0 + 4 * rng.random((B, 4))).astype(np.float32)
+    tol = 1e-13 if exact_hypers else 5e-7
+    K = ops.covariance(to_dev(X), kid, to_dev(raw)).cpu().numpy()
+    N = K.shape[1]
+    assert N == 336
+    for b in range(B):
+        h = ogp.Hypers(*raw[b])
+        noise, _, os_, ls = [v.double() for v in h.constrained()]
+        want = (os_ * ogp.base_kernel(torch.tensor(X[b]), torch.tensor(X[b]), ls, kid)
+                + noise * torch.eye(n, dtype=torch.float64)).detach().numpy()
+        got = K[b]
+        for I in range(N // 112):          # only the lower block-triangle is defined
+            for J in range(I + 1):
+                g = got[I * 112:(I + 1) * 112, J * 112:(J + 1) * 112]
+                w = np.zeros((112, 112))
+                ii, jj = np.arange(I * 112, (I + 1) * 112), np.arange(J * 112, (J + 1) * 112)
+                mi, mj = ii < n, jj < n
+                w[np.ix_(mi, mj)] = want[np.ix_(ii[mi], jj[mj])]
+                if I == J:
+                    for t in range(112):
+                        if ii[t] >= n:
+                            w[t, t] = 1.0
+                assert np.abs(g - w).max() <= tol * np.abs(want).max()
+
+
+def _lower_blocks_to_full(M):
+    """Symmetrise from the lower block-triangle (diagonal blocks are full)."""
+    N = M.shape[0]
+    out = np.array(M)
+    for I in range(N // 112):
+        for J in range(I):
+            out[J * 112:(J + 1) * 112, I * 112:(I + 1) * 112] = M[I * 112:(I + 1) * 112, J * 112:(J + 1) * 112].T
+    return out
+
+
+@pytest.mark.parametrize("N", [112, 224, 336, 784])
+def test_invert_spd(N):
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(N)
+    B = 3
+    A = np.zeros((B, N, N))
+    for b in range(B):
+        Q = rng.normal(size=(N, N + 8))
+        A[b] = Q @ Q.T / N + 0.05 * np.eye(N)
+    At = to_dev(A)
+    logdet, flags = ops.invert_(At)
+    assert int(flags.sum()) == 0
+    for b in range(B):
+        got = -_lower_blocks_to_full(At[b].cpu().numpy())
+        want = np.linalg.inv(A[b])
+        assert np.abs(got - want).max() <= 1e-9 * np.abs(want).max()
+        assert abs(logdet[b].item() - np.linalg.slogdet(A[b])[1]) < 1e-8 * N
+
+
+def test_invert_flags_non_spd():
+    from super_resolution_amd import ops
+    N = 224
+    A = np.stack([np.eye(N), np.eye(N)])
+    A[1, 150, 150] = -1.0
+    _, flags = ops.invert_(to_dev(A))
+    assert flags.cpu().tolist() == [0, 1]
+
+
+@pytest.mark.parametrize("kid,n,d", [(0, 324, 8), (1, 324, 8), (2, 324, 8), (3, 324, 8), (3, 784, 8), (3, 100, 8),
+                                     (4, 500, 49)])
+def test_loss_and_grad_vs_autograd(kid, n, d):
+    """d loss / d raw from the HIP closed form vs torch autograd through Cholesky (the reference's route)."""
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(100 + kid + n)
+    B = 2
+    if d == 8:
+        img = natural_image(40, 40, n + kid)
+        X = np.stack([rng.permutation(opatch.features(img[1:39, 1:39]))[:n] for _ in range(B)]) if n <= 1296 else None
+        y = X[:, :, 0] * 0.5 + X[:, :, 3] * 0.5 + rng.normal(0, 0.01, (B, n))
+    else:
+        X = rng.random((B, n, d)); y = X.mean(-1) + rng.normal(0, 0.02, (B, n))
+    raw = np.array([[-5.0, float(y[b].mean()), -1.0 + 0.3 * b, 0.2 - 0.4 * b] for b in range(B)], dtype=np.float32)
+    loss, grad, flags = ops.loss_grad(to_dev(X), to_dev(y), kid, to_dev(raw))
+    assert int(flags.sum()) == 0
+    for b in range(B):
+        h = ogp.Hypers(*raw[b])
+        l = ogp.neg_mll(h, torch.tensor(X[b]), torch.tensor(y[b]), kid)
+        l.backward()
+        g = np.array([p.grad.item() for p in h.params()])
+        assert abs(loss[b].item() - l.item()) < 1e-9 * max(1, abs(l.item()))
+        got = grad[b].cpu().numpy()
+        assert np.allclose(got, g, rtol=2e-5, atol=1e-7), (got, g)
+
+
+@pytest.mark.parametrize("kid,n", [(0, 324), (3, 324), (2, 324), (1, 324), (3, 784)])
+def test_fit_and_predict_vs_oracle(kid, n):
+    """50 Adam steps + predictive mean on real patch geometry vs the oracle's
+    torch/autograd loop.  Bar: predicted pixels within 1e-4 (<< 1/255); final raw
+    hyper-parameters within 2e-3 (float32 Adam trajectories are not bit-comparable)."""
+    from super_resolution_amd import ops
+    s, p = (2, 20) if n == 324 else (3, 30)
+    H, W = p + 6, p + 9
+    lo = natural_image(H, W, 7 + kid)
+    from oracle import cvops
+    hi = cvops.resize_cubic(lo, fx=s, fy=s)
+    locs = opatch.patch_locations((H, W), p)[:3]
+    tidx = np.arange(1, p - 1, dtype=np.int32)
+    X, y, Xs = ops.gather(to_dev(lo), to_dev(lo), to_dev(hi), s, p, to_dev(np.array(locs, dtype=np.int32)), to_dev(tidx))
+    raw = ops.init_hypers(y, kid)
+    raw0 = raw.cpu().numpy().copy()
+    alpha, flags = ops.fit(X, y, kid, raw, iters=50, lr=0.1)
+    pred = ops.predict(X, Xs, alpha, raw, kid).cpu().numpy()
+    assert int(flags.sum()) == 0
+    for k, loc in enumerate(locs):
+        Xo = opatch.features(opatch.extract(lo, loc, p, 1))
+        yo = opatch.targets(opatch.extract(lo, loc, p, 1))
+        Xso = opatch.features(opatch.extract(hi, loc, p, s))
+        h0 = ogp.init_hypers(torch.tensor(yo), kid)
+        assert np.allclose(raw0[k], h0.as_array(), rtol=1e-5, atol=1e-6), (raw0[k], h0.as_array())
+        mean, rawo = ogp.fit_predict_patch(Xo, yo, Xso, kid)
+        assert np.allclose(raw[k].cpu().numpy(), rawo, rtol=2e-3, atol=2e-3), (raw[k].cpu().numpy(), rawo)
+        assert np.abs(pred[k] - mean).max() < 1e-4
+
+
+def test_fit_constant_patch_rbf():
+    """A flat patch: var(y)=0 -> RBF outputscale init 0 (raw -inf); prediction must be the constant."""
+    from super_resolution_amd import ops
+    n, m = 324, 1444
+    X = torch.full((1, n, 8), 0.5, dtype=torch.float64, device=dev())
+    y = torch.full((1, n), 0.5, dtype=torch.float64, device=dev())
+    Xs = torch.full((1, m, 8), 0.5, dtype=torch.float64, device=dev())
+    for kid in (0, 3):
+        raw = ops.init_hypers(y, kid)
+        alpha, flags = ops.fit(X, y, kid, raw, iters=50)
+        pred = ops.predict(X, Xs, alpha, raw, kid)
+        assert torch.isfinite(pred).all()
+        assert (pred - 0.5).abs().max().item() < 1e-6
