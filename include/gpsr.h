@@ -161,6 +161,32 @@ int gpsr_agpr_weights(const double* X, const double* alpha, const float* raw, in
 int gpsr_agpr_filter(const double* img, int Hs, int Ws, int L, const double* w, const float* raw,
                      double* out, void* stream);
 
+/*
+ * Image stages between the two GP phases, so the image never leaves the GPU
+ * (SURVEY.md 8(f) rank 1).  OpenCV is restated, not linked:
+ *   gpsr_u8_to_unit    img.astype(double)/255            gprsr.py:91, agpr.py:161
+ *   gpsr_unit_to_u8    (img*scale).astype(uint8), truncating   gprsr.py:100
+ *   gpsr_resample      cv.resize INTER_CUBIC (taps=4) / INTER_LINEAR (taps=2) on CV_64F:
+ *                      horizontal then vertical pass with the index/coefficient
+ *                      tables the host computes the way resize.cpp does
+ *                      (gprsr.py:106,115; agpr.py:163,205,246)
+ *   gpsr_decimate2     the INTER_AREA fast path cv.resize takes for fx=fy=1/2  (gprsr.py:115)
+ *   gpsr_sepfilter_sym cv.GaussianBlur on CV_64F: symmetric separable filter,
+ *                      BORDER_REFLECT_101 (gprsr.py:114; agpr.py:245)
+ *   gpsr_filter3x3     cv.filter2D 3x3 correlation, BORDER_REFLECT_101 (agpr.py:206)
+ *   gpsr_axpy          dst = a + alpha*b (agpr.py:207)
+ */
+int gpsr_u8_to_unit(const uint8_t* src, double* dst, size_t n, void* stream);
+int gpsr_unit_to_u8(const double* src, uint8_t* dst, size_t n, double scale, void* stream);
+int gpsr_resample(const double* src, int Hs, int Ws, double* dst, int Hd, int Wd,
+                  const int32_t* xi, const double* xw, const int32_t* yi, const double* yw,
+                  int taps, void* stream);
+int gpsr_decimate2(const double* src, int Hs, int Ws, double* dst, void* stream);
+int gpsr_sepfilter_sym(const double* src, int H, int W, double* dst, const double* kern, int ksize,
+                       void* stream);
+int gpsr_filter3x3(const double* src, int H, int W, double* dst, const double* kern, void* stream);
+int gpsr_axpy(const double* a, const double* b, double alpha, double* dst, size_t n, void* stream);
+
 /* Self-test of the f64 MFMA operand/accumulator lane maps: D = A(16x4) B(4x16),
  * plain row-major inputs and output.  Used by tests only. */
 int gpsr_selftest_mfma(const double* A, const double* Bm, double* D, void* stream);

@@ -332,3 +332,63 @@ extern "C" int gpsr_selftest_mfma(const double* A, const double* Bm, double* D, 
   CHECK_LAUNCH("k_selftest_mfma");
   return 0;
 }
+
+// ---------------------------------------------------------------- image stages
+#define GRID1D(n) dim3((unsigned)(((size_t)(n) + 255) / 256)), dim3(256), 0, (hipStream_t)stream
+
+extern "C" int gpsr_u8_to_unit(const uint8_t* src, double* dst, size_t n, void* stream) {
+  if (!src || !dst) return arg_fail("null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_u8_to_unit, GRID1D(n), src, dst, n);
+  CHECK_LAUNCH("k_u8_to_unit");
+  return 0;
+}
+
+extern "C" int gpsr_unit_to_u8(const double* src, uint8_t* dst, size_t n, double scale, void* stream) {
+  if (!src || !dst) return arg_fail("null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_unit_to_u8, GRID1D(n), src, dst, n, scale);
+  CHECK_LAUNCH("k_unit_to_u8");
+  return 0;
+}
+
+extern "C" int gpsr_resample(const double* src, int Hs, int Ws, double* dst, int Hd, int Wd, const int32_t* xi,
+                             const double* xw, const int32_t* yi, const double* yw, int taps, void* stream) {
+  if (!src || !dst || !xi || !xw || !yi || !yw) return arg_fail("null pointer");
+  if (Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1 || taps < 1 || taps > 8) return arg_fail("resample shape");
+  hipLaunchKernelGGL(k_resample, GRID1D((size_t)Hd * Wd), src, Hs, Ws, dst, Hd, Wd, xi, xw, yi, yw, taps);
+  CHECK_LAUNCH("k_resample");
+  return 0;
+}
+
+extern "C" int gpsr_decimate2(const double* src, int Hs, int Ws, double* dst, void* stream) {
+  if (!src || !dst || Hs < 2 || Ws < 2) return arg_fail("decimate2");
+  const int Hd = Hs / 2, Wd = Ws / 2;
+  hipLaunchKernelGGL(k_decimate2, GRID1D((size_t)Hd * Wd), src, Ws, dst, Hd, Wd);
+  CHECK_LAUNCH("k_decimate2");
+  return 0;
+}
+
+extern "C" int gpsr_sepfilter_sym(const double* src, int H, int W, double* dst, const double* kern, int ksize,
+                                  void* stream) {
+  if (!src || !dst || !kern || H < 1 || W < 1) return arg_fail("sepfilter");
+  if ((ksize & 1) == 0 || ksize < 1 || ksize > 7) return arg_fail("sepfilter ksize (odd, <= 7)");
+  hipLaunchKernelGGL(k_sepfilter_sym, GRID1D((size_t)H * W), src, H, W, dst, kern, ksize / 2);
+  CHECK_LAUNCH("k_sepfilter_sym");
+  return 0;
+}
+
+extern "C" int gpsr_filter3x3(const double* src, int H, int W, double* dst, const double* kern, void* stream) {
+  if (!src || !dst || !kern || H < 1 || W < 1) return arg_fail("filter3x3");
+  hipLaunchKernelGGL(k_filter3x3, GRID1D((size_t)H * W), src, H, W, dst, kern);
+  CHECK_LAUNCH("k_filter3x3");
+  return 0;
+}
+
+extern "C" int gpsr_axpy(const double* a, const double* b, double alpha, double* dst, size_t n, void* stream) {
+  if (!a || !b || !dst) return arg_fail("null pointer");
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_axpy, GRID1D(n), a, b, alpha, dst, n);
+  CHECK_LAUNCH("k_axpy");
+  return 0;
+}

@@ -714,3 +714,96 @@ __global__ void k_selftest_mfma(const double* __restrict__ A, const double* __re
   acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc, 0, 0, 0);
   for (int rr = 0; rr < 4; ++rr) D[((lane >> 4) + 4 * rr) * 16 + (lane & 15)] = acc[rr];
 }
+
+// ------------------------------------------------ image stages between the phases
+// (cv.resize / cv.GaussianBlur / cv.filter2D restated; tables come from the host)
+
+// uint8 -> float64 / 255   (gprsr.py:91)   and   float64 -> uint8 by truncation (gprsr.py:100)
+__global__ void k_u8_to_unit(const uint8_t* __restrict__ src, double* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (double)src[i] / 255.0;
+}
+__global__ void k_unit_to_u8(const double* __restrict__ src, uint8_t* __restrict__ dst, size_t n, double scale) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = (uint8_t)(int)(src[i] * scale);
+}
+
+// Separable resampling with T taps per axis (cubic T=4, linear T=2): horizontal pass
+// then vertical pass, taps added left to right without contraction -- the order of
+// OpenCV's HResize*/VResize* for CV_64F.  xi/yi: source indices (border already
+// replicated), xw/yw: float32 coefficients widened to float64.
+__global__ void k_resample(const double* __restrict__ src, int Hs, int Ws, double* __restrict__ dst, int Hd,
+                           int Wd, const int32_t* __restrict__ xi, const double* __restrict__ xw,
+                           const int32_t* __restrict__ yi, const double* __restrict__ yw, int T) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)Hd * Wd) return;
+  const int r = (int)(idx / Wd), c = (int)(idx % Wd);
+  double acc = 0.0;
+  for (int k = 0; k < T; ++k) {
+    const double* row = src + (size_t)yi[r * T + k] * Ws;
+    double h = __dmul_rn(row[xi[c * T]], xw[c * T]);
+    for (int j = 1; j < T; ++j) h = __dadd_rn(h, __dmul_rn(row[xi[c * T + j]], xw[c * T + j]));
+    const double t = __dmul_rn(h, yw[r * T + k]);
+    acc = (k == 0) ? t : __dadd_rn(acc, t);
+  }
+  dst[idx] = acc;
+}
+
+// exact 2x2 decimation (cv.resize INTER_LINEAR with fx=fy=1/2 takes the INTER_AREA fast path)
+__global__ void k_decimate2(const double* __restrict__ src, int Ws, double* __restrict__ dst, int Hd, int Wd) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)Hd * Wd) return;
+  const int r = (int)(idx / Wd), c = (int)(idx % Wd);
+  const double* p0 = src + (size_t)(2 * r) * Ws + 2 * c;
+  const double* p1 = p0 + Ws;
+  dst[idx] = __dmul_rn(__dadd_rn(__dadd_rn(__dadd_rn(p0[0], p0[1]), p1[0]), p1[1]), 0.25);
+}
+
+__device__ __forceinline__ int reflect101(int i, int n) {
+  if (n == 1) return 0;
+  while (i < 0 || i >= n) i = (i < 0) ? -i : 2 * (n - 1) - i;
+  return i;
+}
+
+// symmetric separable filter, radius h <= 3, BORDER_REFLECT_101, rows then columns
+// (cv.GaussianBlur for CV_64F -> sepFilter2D with SymmRow/SymmColumn filters)
+__global__ void k_sepfilter_sym(const double* __restrict__ src, int H, int W, double* __restrict__ dst,
+                                const double* __restrict__ kern, int h) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)H * W) return;
+  const int r = (int)(idx / W), c = (int)(idx % W);
+  double rowv[7];
+  for (int d = -h; d <= h; ++d) {
+    const double* row = src + (size_t)reflect101(r + d, H) * W;
+    double t = __dmul_rn(row[c], kern[h]);
+    for (int j = 1; j <= h; ++j)
+      t = __dadd_rn(t, __dmul_rn(__dadd_rn(row[reflect101(c + j, W)], row[reflect101(c - j, W)]), kern[h + j]));
+    rowv[d + h] = t;
+  }
+  double o = __dmul_rn(rowv[h], kern[h]);
+  for (int j = 1; j <= h; ++j) o = __dadd_rn(o, __dmul_rn(__dadd_rn(rowv[h + j], rowv[h - j]), kern[h + j]));
+  dst[idx] = o;
+}
+
+// 3x3 correlation, BORDER_REFLECT_101, non-zero taps added in row-major order (cv.filter2D)
+__global__ void k_filter3x3(const double* __restrict__ src, int H, int W, double* __restrict__ dst,
+                            const double* __restrict__ kern) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)H * W) return;
+  const int r = (int)(idx / W), c = (int)(idx % W);
+  double o = 0.0;
+  for (int a = 0; a < 3; ++a)
+    for (int b = 0; b < 3; ++b) {
+      const double kv = kern[a * 3 + b];
+      if (kv != 0.0)
+        o = __dadd_rn(o, __dmul_rn(kv, src[(size_t)reflect101(r + a - 1, H) * W + reflect101(c + b - 1, W)]));
+    }
+  dst[idx] = o;
+}
+
+// dst = a + alpha * b    /   dst = clip(a, 0, 1)    (IBP loop of agpr.py:199-209, clip agpr.py:188)
+__global__ void k_axpy(const double* __restrict__ a, const double* __restrict__ b, double alpha,
+                       double* __restrict__ dst, size_t n) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) dst[i] = __dadd_rn(a[i], __dmul_rn(b[i], alpha));
+}

@@ -1,0 +1,164 @@
+"""GPRSR: drop-in for the reference's gprsr.py on the batched MI355X engine.
+
+Same surface as the reference (gprsr.py:12-26, 37-210): the ColorSpace enum, the
+module-level option constants, extract_patch / extract_neighbors, and
+GPRSR(scaling_factor, used_kernel, color_mode) with apply / apply_for_channel /
+upsample / blur_downsample / deblur / predict_pixels.  numpy arrays in, fresh
+numpy arrays out; internally the image goes to the GPU once and stays there
+through upsample -> blur/downsample -> deblur and through x4 = x2 o x2.
+
+Additional (keyword-only) knobs of the engine: warm_start ("independent" |
+"chain", see engine.py), iters, and the batch entry points
+apply_for_channel_batch / apply_batch that fit the patches of many images in
+one GP batch.
+"""
+import time
+from enum import Enum
+
+import numpy as np
+import torch
+
+from . import engine, imgproc, ops
+from .image_patches import PatchHandler, PatchInterpolationMode  # noqa: F401  (re-exported like the reference)
+from .kernels import (GeneralModel, get_kernel_name, kernel_id_of, linear_kernel,  # noqa: F401
+                      matern32_kernel, matern52_kernel)
+
+
+class ColorSpace(Enum):
+    BGR = 0
+    YUV = 1
+    GRAYSCALE = 2
+
+
+# Options (module constants in the reference, gprsr.py:17-26; main.py exposes them as flags)
+SRF = 2
+IMAGE_NUMS = range(1, 15)
+DO_TIMING = True
+USED_COLOR_SPACE = ColorSpace.GRAYSCALE
+USED_KERNEL = matern52_kernel
+USE_ALL_PIXELS_FOR_TRAINING = True
+LEARNING_RATE = 0.1
+STRIDE_PERCENTAGE = 0.9
+PATCH_INTERPOLATION = PatchInterpolationMode.AVERAGE
+
+
+def extract_patch(img, y, x, patch_size):
+    return img[y:y + patch_size, x:x + patch_size].copy()
+
+
+def extract_neighbors(img, y, x):
+    """8-neighbour feature vector in the reference's order (gprsr.py:35)."""
+    return [img[y + 1, x], img[y - 1, x], img[y, x + 1], img[y, x - 1],
+            img[y + 1, x + 1], img[y - 1, x - 1], img[y + 1, x - 1], img[y - 1, x + 1]]
+
+
+def _device():
+    if not torch.cuda.is_available():
+        raise RuntimeError("GPRSR needs an MI355X (ROCm) device: there is no CPU path in this package")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+class GPRSR:
+    def __init__(self, scaling_factor, used_kernel=matern52_kernel, color_mode=ColorSpace.YUV, *,
+                 warm_start="independent", iters=50, shard=None, max_workspace_bytes=48 << 30):
+        assert warm_start in ("independent", "chain")
+        self.scaling_factor = scaling_factor
+        self.current_scaling_factor = None
+        self.used_kernel = used_kernel
+        self.color_mode = color_mode
+        self.warm_start = warm_start
+        self.iters = iters
+        self.shard = shard
+        self.stats = engine.FitStats()
+        self._gp = engine.BatchedGP(kernel_id_of(used_kernel), iters=iters, lr=LEARNING_RATE,
+                                    max_workspace_bytes=max_workspace_bytes)
+
+    # ------------------------------------------------------------------ colour handling (gprsr.py:48-74)
+    def apply(self, lr_image):
+        if DO_TIMING:
+            start_time = time.time()
+        if self.color_mode == ColorSpace.GRAYSCALE:
+            g = self.apply_for_channel(imgproc.bgr2gray(lr_image))
+            img_out = np.stack([g, g, g], axis=-1)
+        elif self.color_mode == ColorSpace.YUV:
+            y, u, v = imgproc.bgr2yuv(lr_image)
+            y = self.apply_for_channel(y)
+            u = imgproc.resize_cubic_u8(u, fx=self.scaling_factor, fy=self.scaling_factor)
+            v = imgproc.resize_cubic_u8(v, fx=self.scaling_factor, fy=self.scaling_factor)
+            img_out = imgproc.yuv2bgr(y, u, v)
+        else:
+            chans = [self.apply_for_channel(np.ascontiguousarray(lr_image[..., i])) for i in range(3)]
+            img_out = np.stack(chans, axis=-1)
+        if DO_TIMING:
+            print("Upscaling took %s seconds" % (time.time() - start_time), flush=True)
+        return img_out
+
+    # ------------------------------------------------------------------ one channel (gprsr.py:79-100)
+    def apply_for_channel(self, lr_image_channel):
+        return self.apply_for_channel_batch([lr_image_channel])[0]
+
+    def apply_for_channel_batch(self, channels):
+        """Several uint8 channels/images at once: their patches share the GP batches."""
+        dev = _device()
+        imgs = [ops.u8_to_unit(torch.as_tensor(np.ascontiguousarray(c, dtype=np.uint8)).to(dev)) for c in channels]
+        outs = self.apply_for_channel_device(imgs)
+        res = [ops.unit_to_u8(o, 255.0).cpu().numpy() for o in outs]
+        return res
+
+    def apply_for_channel_device(self, imgs):
+        """Device float64 images in [0,1] -> device float64 HR images (before the uint8 cast)."""
+        scaling_factor = self.scaling_factor
+        while scaling_factor >= 4:
+            scaling_factor /= 2
+            imgs = self._do_algorithm(imgs, 2)
+        return self._do_algorithm(imgs, scaling_factor)
+
+    def _do_algorithm(self, imgs, scaling_factor):
+        self.current_scaling_factor = scaling_factor
+        if self.warm_start == "chain" and len(imgs) > 1:
+            # the chain runs image by image: upsample(i), deblur(i), upsample(i+1), ...
+            return [self._do_algorithm([im], scaling_factor)[0] for im in imgs]
+        blurred_high = self._upsample(imgs)
+        blurred_low = [self._blur_downsample(b) for b in blurred_high]
+        return self._predict_pixels(list(zip(blurred_low, imgs, blurred_high)))
+
+    def _s_int(self):
+        s = self.current_scaling_factor
+        assert float(s) == int(s), "the patch pipeline needs an integer step factor (2 or 3)"
+        return int(s)
+
+    def _upsample(self, imgs):
+        s = self.current_scaling_factor
+        bic = [imgproc.resize_cubic(im, fx=s, fy=s) for im in imgs]
+        return self._predict_pixels(list(zip(imgs, imgs, bic)))
+
+    def _blur_downsample(self, img):
+        s = self.current_scaling_factor
+        return imgproc.resize_linear(imgproc.gaussian_blur(img, 5, 0), 1 / s, 1 / s)
+
+    def _predict_pixels(self, jobs):
+        s = self._s_int()
+        p = int(self.current_scaling_factor * 10)
+        mode = PATCH_INTERPOLATION.value
+        chain = self.used_kernel if (self.warm_start == "chain" and self._gp.kernel_id != ops.RBF) else None
+        return engine.predict_pixels_batch(jobs, s, p, self._gp, STRIDE_PERCENTAGE, USE_ALL_PIXELS_FOR_TRAINING,
+                                           mode, chain_kernel=chain, stats=self.stats, shard=self.shard)
+
+    # ------------------------------------------------------------------ reference-named numpy methods
+    def _to_dev(self, a):
+        return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(_device())
+
+    def upsample(self, img):
+        return self._upsample([self._to_dev(img)])[0].cpu().numpy()
+
+    def blur_downsample(self, img):
+        return self._blur_downsample(self._to_dev(img)).cpu().numpy()
+
+    def deblur(self, blurred_high, blurred_low, low):
+        return self.predict_pixels(blurred_low, low, blurred_high)
+
+    def predict_pixels(self, training_input, training_target, test_input):
+        assert training_input.shape == training_target.shape
+        assert test_input.shape[0] == training_input.shape[0] * self.current_scaling_factor
+        job = (self._to_dev(training_input), self._to_dev(training_target), self._to_dev(test_input))
+        return self._predict_pixels([job])[0].cpu().numpy()

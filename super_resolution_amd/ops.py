@@ -164,3 +164,64 @@ def selftest_mfma(A, Bm):
     _lib.check(lib.gpsr_selftest_mfma(_p(A, torch.float64), _p(Bm, torch.float64), _p(D), _stream()),
                "gpsr_selftest_mfma")
     return D
+
+
+# ------------------------------------------------------------ image stages
+def u8_to_unit(img_u8):
+    lib = _lib.load()
+    out = torch.empty(img_u8.shape, dtype=torch.float64, device=img_u8.device)
+    _lib.check(lib.gpsr_u8_to_unit(_p(img_u8, torch.uint8), _p(out), img_u8.numel(), _stream()), "gpsr_u8_to_unit")
+    return out
+
+
+def unit_to_u8(img, scale=255.0):
+    lib = _lib.load()
+    out = torch.empty(img.shape, dtype=torch.uint8, device=img.device)
+    _lib.check(lib.gpsr_unit_to_u8(_p(img, torch.float64), _p(out), img.numel(), float(scale), _stream()),
+               "gpsr_unit_to_u8")
+    return out
+
+
+def resample(img, Hd, Wd, xi, xw, yi, yw):
+    lib = _lib.load()
+    Hs, Ws = img.shape
+    taps = xi.shape[1]
+    out = torch.empty((Hd, Wd), dtype=torch.float64, device=img.device)
+    _lib.check(lib.gpsr_resample(_p(img, torch.float64), Hs, Ws, _p(out), Hd, Wd, _p(xi, torch.int32),
+                                 _p(xw, torch.float64), _p(yi, torch.int32), _p(yw, torch.float64), taps,
+                                 _stream()), "gpsr_resample")
+    return out
+
+
+def decimate2(img):
+    lib = _lib.load()
+    Hs, Ws = img.shape
+    out = torch.empty((Hs // 2, Ws // 2), dtype=torch.float64, device=img.device)
+    _lib.check(lib.gpsr_decimate2(_p(img, torch.float64), Hs, Ws, _p(out), _stream()), "gpsr_decimate2")
+    return out
+
+
+def sepfilter_sym(img, kern):
+    lib = _lib.load()
+    H, W = img.shape
+    out = torch.empty_like(img)
+    _lib.check(lib.gpsr_sepfilter_sym(_p(img, torch.float64), H, W, _p(out), _p(kern, torch.float64), kern.numel(),
+                                      _stream()), "gpsr_sepfilter_sym")
+    return out
+
+
+def filter3x3(img, kern):
+    lib = _lib.load()
+    H, W = img.shape
+    out = torch.empty_like(img)
+    _lib.check(lib.gpsr_filter3x3(_p(img, torch.float64), H, W, _p(out), _p(kern, torch.float64), _stream()),
+               "gpsr_filter3x3")
+    return out
+
+
+def axpy(a, b, alpha):
+    lib = _lib.load()
+    out = torch.empty_like(a)
+    _lib.check(lib.gpsr_axpy(_p(a, torch.float64), _p(b, torch.float64), float(alpha), _p(out), a.numel(), _stream()),
+               "gpsr_axpy")
+    return out
