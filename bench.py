@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the batched SRGPR engine.
+
+Metric (BASELINE.json): output megapixels / second of SR x3 with the Matern-5/2
+kernel.  Workload at N=1 = BASELINE.json configs[1]: the full Set14 x3 set
+(14 LR images of the Set14 image_SRF_3 shapes, GRAYSCALE, 633 patches, 1266 GP
+fits of n=784, m=7744 each, 3.2066 output Mpx) -- synthetic images of exactly
+those shapes (the reference's PNGs do not travel to the GPU box).
+
+A "step" = one pass of GPRSR.apply_for_channel over the whole batch (both
+phases: gather -> 50-step Adam fit -> predictive mean -> recombination, plus
+the bicubic / blur / decimation stages between them), inputs resident in HBM as
+float64 images when the clock starts, uint8 HR images in HBM when it stops.
+
+N > 1 (weak scaling): the batch is N copies of the workload (different seeds);
+the global patch list is sharded over the ranks (super_resolution_amd/dist.py)
+and the predicted patches are all-gathered over RCCL; value = all output
+megapixels / max-over-ranks time.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with
+  roofline     : the dominant kernel (k_update, f64 MFMA tile products), HIP-event timed
+  cpu_baseline : the CPU oracle (torch f64 restatement of the GPyTorch loop) on a bounded sample
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+# LR shapes (H, W) of Set14/image_SRF_3/img_001..014_SRF_3_LR.png
+SET14_X3_LR_SHAPES = [(160, 166), (192, 240), (170, 170), (96, 117), (120, 83), (92, 92), (120, 166),
+                      (96, 117), (170, 170), (170, 170), (170, 256), (170, 170), (218, 176), (130, 195)]
+FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (AMD spec; the microarch guide lists no f64 row)
+NB = 112
+
+
+def synthetic_lr(H, W, seed):
+    """Natural-like uint8 image (SURVEY.md 8(d) generator): smooth field + edges + noise."""
+    from scipy.ndimage import gaussian_filter
+    rng = np.random.default_rng(seed)
+    img = gaussian_filter(rng.random((H, W)), 3.0)
+    img = (img - img.min()) / (img.max() - img.min()) * 219 + 16
+    img += rng.normal(0, 2, (H, W))
+    yy, xx = np.mgrid[0:H, 0:W]
+    for _ in range(8):
+        a, b, c = rng.normal(size=3)
+        img += rng.uniform(-30, 30) * ((a * (yy - H / 2) + b * (xx - W / 2) + 0.2 * c * max(H, W)) > 0)
+    return np.clip(np.rint(img), 0, 255).astype(np.uint8)
+
+
+def workload(name, copies):
+    if name == "set14x3":
+        shapes, s = SET14_X3_LR_SHAPES, 3
+    elif name == "4kx2":
+        shapes, s = [(2160, 3840)], 2
+    elif name == "tiny":
+        shapes, s = [(47, 39), (40, 52)], 3
+    else:
+        raise SystemExit(f"unknown workload {name}")
+    imgs = []
+    for c in range(copies):
+        for i, (H, W) in enumerate(shapes):
+            imgs.append(synthetic_lr(H, W, 1234 + 100 * c + i))
+    return imgs, s
+
+
+def patch_count(shape, s):
+    p = 10 * s
+    stride = int((p - 2) * 0.9)
+    return len(range(0, shape[0], stride)) * len(range(0, shape[1], stride))
+
+
+def cpu_baseline(kernel_id, s, seconds_budget=20.0):
+    """Oracle (CPU restatement of the reference's per-patch GPyTorch loop) timed on a
+    bounded sample of the same workload: whole patch fits (n=(10s-2)^2, m=(10s^2-2)^2)."""
+    from oracle import gp as ogp, patches as opatch, cvops
+    cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    p = 10 * s
+    lr = synthetic_lr(p + 4, p + 4, 77).astype(np.double) / 255.
+    hi = cvops.resize_cubic(lr, fx=s, fy=s)
+    locs = opatch.patch_locations(lr.shape, p)
+    t0, done = time.time(), 0
+    while done < len(locs) and (done == 0 or (time.time() - t0) * (done + 1) / done < seconds_budget):
+        loc = locs[done]
+        X = opatch.features(opatch.extract(lr, loc, p, 1))
+        y = opatch.targets(opatch.extract(lr, loc, p, 1))
+        Xs = opatch.features(opatch.extract(hi, loc, p, s))
+        ogp.fit_predict_patch(X, y, Xs, kernel_id)
+        done += 1
+    dt = time.time() - t0
+    return dt / done, done, cores
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--workload", default="set14x3")
+    ap.add_argument("--kernel", default="matern52")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--max-workspace-gb", type=float, default=48.0)
+    a = ap.parse_args()
+
+    from super_resolution_amd import dist as gdist
+    rank, world, local = gdist.init_from_env()
+    if world != a.gpus and world > 1:
+        raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    from super_resolution_amd import kernels as K, ops
+    from super_resolution_amd.gprsr import GPRSR, ColorSpace
+    kern = {"matern52": K.matern52_kernel, "matern32": K.matern32_kernel, "rbf": K.rbf_kernel,
+            "exponential": K.exponential_kernel}[a.kernel]
+    if a.workload == "4kx2" and a.kernel == "matern52":
+        kern = K.matern32_kernel  # BASELINE.json config 4
+    imgs_u8, s = workload(a.workload, world)
+    out_px = sum(im.shape[0] * s * im.shape[1] * s for im in imgs_u8)
+    n_patches = sum(patch_count(im.shape, s) for im in imgs_u8)
+    g = GPRSR(s, kern, ColorSpace.GRAYSCALE, shard=(rank, world) if world > 1 else None,
+              max_workspace_bytes=int(a.max_workspace_gb * (1 << 30)))
+    imgs = [ops.u8_to_unit(torch.as_tensor(im).to(dev)) for im in imgs_u8]
+
+    def step():
+        outs = g.apply_for_channel_device(imgs)
+        return [ops.unit_to_u8(o, 255.0) for o in outs]
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(a.warmup):
+        step()
+    barrier()
+    if rank == 0:
+        ops.profile_begin(1 << 16)
+    t0 = time.perf_counter()
+    for _ in range(a.steps):
+        outs = step()
+    barrier()
+    dt = time.perf_counter() - t0
+    prof = ops.profile_end() if rank == 0 else None
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+    flags_bad = int(sum(int(f.sum()) for f in g.stats.flags))
+
+    if rank != 0:
+        return
+    ms_per_step = dt / a.steps * 1e3
+    value = out_px / 1e6 / (dt / a.steps)
+
+    # roofline of the dominant kernel: k_update = batched 112x112x112 f64 MFMA tile products.
+    # Algorithmic flops of one launch (pivot step of B GPs, symmetric): B * (N-NB)^2 * NB.
+    n = (10 * s - 2) ** 2
+    N = -(-n // NB) * NB
+    cnt, ms = prof["update"]
+    B_local = -(-n_patches // world)
+    flops_launch = B_local * (N - NB) ** 2 * NB
+    avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
+    achieved = flops_launch / avg_s / 1e12 if cnt else float("nan")
+    kernel_ms = {k: round(v[1] / a.steps, 3) for k, v in prof.items()}
+    roofline = {"kernel": "k_update", "bound": "mfma", "achieved": round(achieved, 3),
+                "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
+                "traffic": None, "launches_per_step": cnt // max(1, a.steps), "avg_launch_ms": round(avg_s * 1e3, 4),
+                "flops_per_launch": flops_launch, "kernel_ms_per_step": kernel_ms}
+
+    cpu = None
+    if not a.no_cpu_baseline:
+        sec_per_fit, nfit, cores = cpu_baseline(g._gp.kernel_id, s)
+        fits = 2 * n_patches // world  # per copy of the workload
+        cpu_val = (out_px / world) / 1e6 / (sec_per_fit * fits)
+        cpu = {"value": round(cpu_val, 6), "unit": "output Mpx/s", "cores": cores, "kind": "port",
+               "sample": f"{nfit} whole patch fits (n={n}, 50 Adam steps + predictive mean, m={(10 * s * s - 2) ** 2}) "
+                         f"of the oracle's torch-f64 per-patch loop, {sec_per_fit:.2f} s/fit, extrapolated "
+                         f"linearly to the workload's {fits} fits (patch gather/recombination not counted)"}
+
+    line = {"metric": "output megapixels/sec (SR x3, Matern-5/2)" if a.workload == "set14x3" else
+            f"output megapixels/sec ({a.workload}, {a.kernel})",
+            "value": round(value, 4), "unit": "Mpx/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": f"{a.workload}: {len(imgs_u8)} images, {n_patches} patches, "
+                                   f"{2 * n_patches} GP fits (n={n}), {out_px / 1e6:.4f} output Mpx",
+                       "kernel": a.kernel if not (a.workload == '4kx2' and a.kernel == 'matern52') else 'matern32',
+                       "color": "GRAYSCALE", "warm_start": "independent",
+                       "parallelism": f"patch-sharded x{world}"},
+            "nonpositive_pivot_flags": flags_bad,
+            "roofline": roofline, "cpu_baseline": cpu}
+    if cpu:
+        line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
+    print(json.dumps(line), flush=True)
+
+
+if __name__ == "__main__":
+    main()

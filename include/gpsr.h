@@ -187,6 +187,20 @@ int gpsr_sepfilter_sym(const double* src, int H, int W, double* dst, const doubl
 int gpsr_filter3x3(const double* src, int H, int W, double* dst, const double* kern, void* stream);
 int gpsr_axpy(const double* a, const double* b, double alpha, double* dst, size_t n, void* stream);
 
+/*
+ * Kernel timing for bench.py's roofline line: HIP-event brackets around the
+ * tagged launches, on the stream they are launched on.  No counterpart in the
+ * reference (its only instrumentation is time.time() per image, gprsr.py:49-72).
+ * gpsr_profile_end waits for the recorded events and fills counts[] / total_ms[]
+ * (GPSR_PROFILE_NTAGS entries each).  Not thread-safe; one profiling session at a time.
+ */
+enum {
+  GPSR_PROF_UPDATE = 0, GPSR_PROF_PANEL, GPSR_PROF_PIVOT, GPSR_PROF_BUILD,
+  GPSR_PROF_GRAD1, GPSR_PROF_GRAD2, GPSR_PROF_PREDICT, GPSR_PROFILE_NTAGS
+};
+int gpsr_profile_begin(int max_records);
+int gpsr_profile_end(int32_t* counts, double* total_ms);
+
 /* Self-test of the f64 MFMA operand/accumulator lane maps: D = A(16x4) B(4x16),
  * plain row-major inputs and output.  Used by tests only. */
 int gpsr_selftest_mfma(const double* A, const double* Bm, double* D, void* stream);

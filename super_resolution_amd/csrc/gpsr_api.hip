@@ -25,6 +25,56 @@ static int arg_fail(const char* what) {
 
 static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 
+// ---------------------------------------------------------------- kernel timing (bench.py roofline)
+// Optional HIP-event brackets around tagged launches, on the stream the kernel is
+// launched on.  Off by default; costs two hipEventRecord per tagged launch when on.
+#include <vector>
+enum { T_UPDATE = 0, T_PANEL, T_PIVOT, T_BUILD, T_GRAD1, T_GRAD2, T_PREDICT, T_NTAGS };
+struct ProfRec { hipEvent_t a, b; int tag; };
+static std::vector<ProfRec> g_prof;
+static size_t g_prof_used = 0;
+static bool g_prof_on = false;
+
+static inline ProfRec* prof_start(int tag, hipStream_t st) {
+  if (!g_prof_on || g_prof_used >= g_prof.size()) return nullptr;
+  ProfRec* r = &g_prof[g_prof_used++];
+  r->tag = tag;
+  (void)hipEventRecord(r->a, st);
+  return r;
+}
+static inline void prof_stop(ProfRec* r, hipStream_t st) { if (r) (void)hipEventRecord(r->b, st); }
+
+extern "C" int gpsr_profile_begin(int max_records) {
+  if (max_records < 1 || max_records > (1 << 20)) return arg_fail("max_records");
+  while ((int)g_prof.size() < max_records) {
+    ProfRec r; r.tag = -1;
+    if (hipEventCreate(&r.a) != hipSuccess || hipEventCreate(&r.b) != hipSuccess) return hip_fail(hipGetLastError(), "hipEventCreate");
+    g_prof.push_back(r);
+  }
+  g_prof_used = 0;
+  g_prof_on = true;
+  return 0;
+}
+
+// Stops recording, waits for the recorded events and returns per-tag launch counts and
+// total milliseconds (arrays of GPSR_PROFILE_NTAGS entries).
+extern "C" int gpsr_profile_end(int32_t* counts, double* total_ms) {
+  g_prof_on = false;
+  if (!counts || !total_ms) return arg_fail("null pointer");
+  for (int t = 0; t < T_NTAGS; ++t) { counts[t] = 0; total_ms[t] = 0.0; }
+  for (size_t i = 0; i < g_prof_used; ++i) {
+    hipError_t e = hipEventSynchronize(g_prof[i].b);
+    if (e != hipSuccess) return hip_fail(e, "hipEventSynchronize");
+    float ms = 0.f;
+    e = hipEventElapsedTime(&ms, g_prof[i].a, g_prof[i].b);
+    if (e != hipSuccess) return hip_fail(e, "hipEventElapsedTime");
+    counts[g_prof[i].tag] += 1;
+    total_ms[g_prof[i].tag] += (double)ms;
+  }
+  g_prof_used = 0;
+  return 0;
+}
+
 extern "C" const char* gpsr_version(void) { return "gpsr 0.1 gfx950"; }
 extern "C" const char* gpsr_last_error(void) { return g_err; }
 extern "C" int gpsr_padded_n(int n) { return ((n + NB - 1) / NB) * NB; }
@@ -69,6 +119,7 @@ static int launch_build(const double* X, int B, int n, int N, int d, int kid, co
   const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2, total = ntri * B;
   const size_t lds = build_lds(d);
 #define BUILD(K) hipLaunchKernelGGL((k_build<K>), dim3(total), dim3(256), lds, st, X, raw, A, n, N, d, ntri, total, logdet)
+  ProfRec* pr = prof_start(T_BUILD, st);
   switch (kid) {
     case K_RBF: BUILD(K_RBF); break;
     case K_M12: BUILD(K_M12); break;
@@ -76,6 +127,7 @@ static int launch_build(const double* X, int B, int n, int N, int d, int kid, co
     case K_M52: BUILD(K_M52); break;
     default: BUILD(K_LIN); break;
   }
+  prof_stop(pr, st);
 #undef BUILD
   CHECK_LAUNCH("k_build");
   return 0;
@@ -90,31 +142,45 @@ extern "C" int gpsr_covariance(const double* X, int B, int n, int d, int kernel_
 }
 
 // ---------------------------------------------------------------- inversion
-struct InvWs { double *Wn, *Wo, *P; };
+struct InvWs { double *Wn, *Wo, *U, *M; };
 
 static size_t inv_ws_bytes(int B, int N) {
-  return 2 * align256((size_t)B * NB * N * 8) + align256((size_t)B * NB * NB * 8);
+  return 2 * align256((size_t)B * NB * N * 8) + 2 * align256((size_t)B * NB * NB * 8);
 }
 static InvWs inv_ws_carve(char* base, int B, int N) {
   InvWs w;
   w.Wn = (double*)base; base += align256((size_t)B * NB * N * 8);
   w.Wo = (double*)base; base += align256((size_t)B * NB * N * 8);
-  w.P = (double*)base;
+  w.U = (double*)base; base += align256((size_t)B * NB * NB * 8);
+  w.M = (double*)base;
   return w;
 }
 
 // sweeps every pivot block of B matrices; logdet must have been zeroed
 static int launch_sweeps(double* A, int B, int N, const InvWs& w, double* logdet, int32_t* flags, hipStream_t st) {
   const int nblk = N / NB;
+  static bool lds_attr_set = false;
+  if (!lds_attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_pivot, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)PIVOT_LDS_BYTES);
+    if (e != hipSuccess) return hip_fail(e, "pivot lds attr");
+    lds_attr_set = true;
+  }
   for (int k = 0; k < nblk; ++k) {
-    hipLaunchKernelGGL(k_pivot, dim3(B), dim3(MM_THREADS), 0, st, A, N, k, w.P, logdet, flags);
+    ProfRec* pr = prof_start(T_PIVOT, st);
+    hipLaunchKernelGGL(k_pivot, dim3(B), dim3(MM_THREADS), PIVOT_LDS_BYTES, st, A, N, k, w.U, w.M, logdet, flags);
+    prof_stop(pr, st);
     CHECK_LAUNCH("k_pivot");
     if (nblk > 1) {
       const int tp = (nblk - 1) * B;
-      hipLaunchKernelGGL(k_panel, dim3(tp), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.P, w.Wn, w.Wo, tp);
+      pr = prof_start(T_PANEL, st);
+      hipLaunchKernelGGL(k_panel, dim3(tp), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.U, w.Wn, w.Wo, tp);
+      prof_stop(pr, st);
       CHECK_LAUNCH("k_panel");
-      const int ntri1 = (nblk - 1) * nblk / 2, tu = ntri1 * B;
-      hipLaunchKernelGGL(k_update, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wn, w.Wo, ntri1, tu);
+      const int ntri1 = (nblk - 1) * nblk / 2, tu = (ntri1 + nblk - 1) * B;
+      pr = prof_start(T_UPDATE, st);
+      hipLaunchKernelGGL(k_update, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wn, w.Wo, w.M, ntri1, tu);
+      prof_stop(pr, st);
       CHECK_LAUNCH("k_update");
     }
   }
@@ -174,6 +240,7 @@ static int launch_grad2(const FitWs& w, const double* X, const float* raw, const
   const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2, total = ntri * B;
   const size_t lds = build_lds(d) + 2 * NB * sizeof(double);
 #define G2(K) hipLaunchKernelGGL((k_grad2<K>), dim3(total), dim3(256), lds, st, w.A, X, raw, alpha, n, N, d, ntri, total, w.stats2)
+  ProfRec* pr = prof_start(T_GRAD2, st);
   switch (kid) {
     case K_RBF: G2(K_RBF); break;
     case K_M12: G2(K_M12); break;
@@ -181,6 +248,7 @@ static int launch_grad2(const FitWs& w, const double* X, const float* raw, const
     case K_M52: G2(K_M52); break;
     default: G2(K_LIN); break;
   }
+  prof_stop(pr, st);
 #undef G2
   CHECK_LAUNCH("k_grad2");
   return 0;
@@ -195,7 +263,9 @@ static int eval_once(const FitWs& w, const double* X, const double* y, const flo
   if (rc) return rc;
   const int nblk = N / NB;
   const size_t lds1 = (size_t)(N + 5 * NB + 32) * sizeof(double);
+  ProfRec* pr = prof_start(T_GRAD1, st);
   hipLaunchKernelGGL(k_grad1, dim3(nblk, B), dim3(MM_THREADS), lds1, st, w.A, N, n, nblk, y, raw, alpha, w.stats1);
+  prof_stop(pr, st);
   CHECK_LAUNCH("k_grad1");
   if (with_grad) return launch_grad2(w, X, raw, alpha, B, n, N, d, kid, st);
   return 0;
@@ -282,6 +352,7 @@ extern "C" int gpsr_predict(const double* X, const double* Xs, const double* alp
     }                                                                                                       \
     hipLaunchKernelGGL((k_predict<K>), grid, dim3(256), lds, st, X, Xs, alpha, raw, n, N, m, out);          \
   } while (0)
+  ProfRec* pr = prof_start(T_PREDICT, st);
   switch (kernel_id) {
     case K_RBF: PR(K_RBF); break;
     case K_M12: PR(K_M12); break;
@@ -289,6 +360,7 @@ extern "C" int gpsr_predict(const double* X, const double* Xs, const double* alp
     case K_M52: PR(K_M52); break;
     default: PR(K_LIN); break;
   }
+  prof_stop(pr, st);
 #undef PR
   CHECK_LAUNCH("k_predict");
   return 0;

@@ -3,15 +3,16 @@
 // Layout conventions
 //   A      [B][N][N] f64 row-major, N = nblk*NB.  Only block (I,J) with I>=J is
 //          maintained ("lower block-triangle"); diagonal blocks are kept full.
-//   Wn, Wo [B][NB][N]  k-major panels of the current pivot step:
-//          Wo[kk][r] = old A[r][k0+kk],  Wn[kk][r] = -(A_.k P)[r][kk]
-//   Pbuf   [B][NB][NB] inverse of the current pivot block
+//   Wn, Wo [B][NB][N]  k-major panels of the current pivot step, W = A_.k L^-T:
+//          Wo[kk][r] = W[r][kk],  Wn = -Wo
+//   U, M   [B][NB][NB] U = L^-T (upper), M = L^-1 (lower) of the current pivot block A_kk = L L^T
 //   raw    [B][4] f32  raw hyper-parameters (noise, const, outputscale, lengthscale)
 //
-// Inversion = blocked symmetric Gauss-Jordan sweep (Goodnight's SWP operator):
-//   for each pivot block k:  P = A_kk^-1 ; A_ik <- A_ik P (i != k) ; A_kk <- -P ;
-//                            A_ij <- A_ij - A_ik P A_kj  (i,j != k)
-// after all pivots A = -A^-1 and sum log(pivots) = log det A.  Total work n^3
+// Inversion = blocked symmetric Gauss-Jordan sweep (Goodnight's SWP operator) in
+// Cholesky form:  for each pivot block k, with A_kk = L L^T:
+//   W_i = A_ik L^-T (i != k) ; A_ij <- A_ij - W_i W_j^T (i,j != k) ;
+//   A_ik <- W_i L^-1 ; A_kk <- -(L L^T)^-1
+// after all pivots A = -A^-1 and sum log(pivots) = log det A.  Total work ~n^3
 // flops, all of it in 112x112x112 f64 MFMA tile products.
 #pragma once
 #include <hip/hip_runtime.h>
@@ -196,113 +197,266 @@ __global__ void k_build(const double* __restrict__ X, const float* __restrict__ 
 }
 
 // ------------------------------------------------------------ pivot block
-// One workgroup (448 threads) per GP.  Thread t owns column l = t % NB and rows
-// rg + 4c (rg = t / NB, c = 0..27) of the NBxNB pivot block in registers and runs
-// the unblocked symmetric sweep with one barrier per pivot.
+// One workgroup (7 waves) per GP factors the NBxNB pivot block S = A_kk in LDS:
+//   phase 1  blocked Cholesky S = L L^T (16x16 sub-blocks; every wave factors the
+//            16x16 diagonal sub-block redundantly in registers, so inv(L16)^T is at
+//            hand as the B operand of the sub-panel product with no LDS hand-off)
+//   phase 2  M = L^-1 by block forward substitution (wave q owns column block q);
+//            M^T =: U is kept in the (otherwise unused) strictly-upper blocks of S
+//   phase 3  P = M^T M = U U^T  ->  A_kk <- -P   (the pivot block of -A^-1)
+//   phase 4  U and M go to global for the panel / update kernels.
+// Everything outside the 16x16 register kernels is f64 MFMA.  Cholesky form on both
+// levels (W = T L^-T, A -= W W^T, T <- W L^-1) keeps the error at the level of an
+// unblocked sweep; forming A -= (T P) T^T with an explicit block inverse loses
+// sqrt(cond) digits per level (measured: DESIGN.md "Numerics of the inversion").
+#define PV_LD 113
+#define PV_DLD 17
+
+// In registers, C/D lane layout (lane: lr = lane&15, lk = lane>>4; a[c] = D[lk+4c][lr]):
+// a <- L16 = chol(D) (zeros above the diagonal), m <- inv(L16); *ld += log det D.
+__device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, double* ld, int* bad) {
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) m[c] = (lk + 4 * c == lr) ? 1.0 : 0.0;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int jr = j & 3, jc = j >> 2;
+    const double pv = __shfl(a[jc], j + 16 * jr);    // D[j][j]
+    const double cl = __shfl(a[jc], lr + 16 * jr);   // D[j][lr]   (row j; used for lr > j)
+    const double mj = __shfl(m[jc], lr + 16 * jr);   // M[j][lr]
+    double ci[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) ci[c] = __shfl(a[c], j + 16 * lk);  // D[lk+4c][j] (column j)
+    if (!(pv > 0.0)) *bad = 1;
+    *ld += log(pv);
+    const double rinv = 1.0 / sqrt(pv);
+    const double clr = cl * rinv;   // L[lr][j]
+    const double mjs = mj * rinv;   // row j of M, final
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int i = lk + 4 * c;
+      const double lij = ci[c] * rinv;  // L[i][j] (i >= j)
+      double av = a[c];
+      if (lr == j) av = (i >= j) ? lij : 0.0;
+      else if (lr > j && i > j) av = fma(-lij, clr, av);
+      a[c] = av;
+      double mv = m[c];
+      if (i > j) mv = fma(-lij, mjs, mv);
+      if (c == jc && lk == jr) mv = mjs;
+      m[c] = mv;
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+    if (lr > lk + 4 * c) a[c] = 0.0;
+}
+
 __global__ void __launch_bounds__(MM_THREADS)
-k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Pbuf,
+k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double* __restrict__ Mbuf,
         double* __restrict__ logdet, int32_t* __restrict__ flags) {
-  __shared__ double colbuf[2][NB];
-  const int b = blockIdx.x, tid = threadIdx.x;
-  const int l = tid % NB, rg = tid / NB;
+  extern __shared__ double sm[];
+  double* S = sm;                          // [NB][PV_LD]
+  double* Dinv = sm + NB * PV_LD;          // [NBT][16][PV_DLD]  inv(L16_q), [row][col]
+  double* Tr = Dinv + NBT * 16 * PV_DLD;   // [NBT waves][16][PV_DLD] per-wave transpose scratch
+  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
   double* Akk = A + (size_t)b * N * N + (size_t)(k * NB) * N + k * NB;
-  double a[28];
-#pragma unroll
-  for (int c = 0; c < 28; ++c) a[c] = Akk[(size_t)(rg + 4 * c) * N + l];
-  double ld = 0.0;
-  int bad = 0;
-  if (l == 0) {
-#pragma unroll
-    for (int c = 0; c < 28; ++c) colbuf[0][rg + 4 * c] = a[c];
+  for (int e = tid; e < NB * NB; e += MM_THREADS) {
+    const int i = e / NB, j = e % NB;
+    S[i * PV_LD + j] = Akk[(size_t)i * N + j];
   }
   __syncthreads();
-  for (int j = 0; j < NB; ++j) {
-    const double* cb = colbuf[j & 1];
-    const double pv = cb[j];
-    if (!(pv > 0.0)) bad = 1;
-    ld += log(pv);
-    const double inv = 1.0 / pv;
-    const double cl = cb[l];
-    const double clinv = cl * inv;
-    const bool lj = (l == j);
+  double ld = 0.0;
+  int bad = 0;
+  double* tr = Tr + wave * 16 * PV_DLD;
+  // ---------------- phase 1: blocked Cholesky
+  for (int q = 0; q < NBT; ++q) {
+    double a[4], m[4];
 #pragma unroll
-    for (int c = 0; c < 28; ++c) {
-      const int i = rg + 4 * c;
-      const double ci = cb[i];
-      double upd = lj ? ci * inv : fma(-ci, clinv, a[c]);
-      double rowj = lj ? -inv : clinv;
-      a[c] = (i == j) ? rowj : upd;
+    for (int c = 0; c < 4; ++c) a[c] = S[(16 * q + lk + 4 * c) * PV_LD + 16 * q + lr];
+    chol16_inv(a, m, lane, &ld, &bad);
+    if (wave == q) {
+      // only inv(L16) is needed later; S[q,q] itself must stay untouched here: slower
+      // waves may still be loading it for their own (redundant) factorisation
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Dinv[(q * 16 + lk + 4 * c) * PV_DLD + lr] = m[c];
+    } else if (wave > q) {
+      // L_wq = S[w,q] * inv(L16)^T : B operand element (k, col) = m16[col][k] -> transpose via scratch
+#pragma unroll
+      for (int c = 0; c < 4; ++c) tr[(lk + 4 * c) * PV_DLD + lr] = m[c];
+      __builtin_amdgcn_wave_barrier();
+      v4d cw = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const double av = S[(16 * wave + lr) * PV_LD + 16 * q + lk + 4 * ks];
+        const double bv = tr[lr * PV_DLD + lk + 4 * ks];
+        cw = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, cw, 0, 0, 0);
+      }
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) S[(16 * wave + lk + 4 * c) * PV_LD + 16 * q + lr] = cw[c];
     }
-    if (l == j + 1) {  // publish next pivot column
+    __syncthreads();
+    if (wave > q) {
+      double an[4];
 #pragma unroll
-      for (int c = 0; c < 28; ++c) colbuf[(j + 1) & 1][rg + 4 * c] = a[c];
+      for (int ks = 0; ks < 4; ++ks) an[ks] = -S[(16 * wave + lr) * PV_LD + 16 * q + lk + 4 * ks];
+      for (int j = q + 1; j <= wave; ++j) {
+        v4d acc;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[c] = S[(16 * wave + lk + 4 * c) * PV_LD + 16 * j + lr];
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const double bv = S[(16 * j + lr) * PV_LD + 16 * q + lk + 4 * ks];
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(an[ks], bv, acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S[(16 * wave + lk + 4 * c) * PV_LD + 16 * j + lr] = acc[c];
+      }
     }
     __syncthreads();
   }
-  double* Pb = Pbuf + (size_t)b * NB * NB;
+  // ---------------- phase 2: M = L^-1, column block q = wave; U[q,w] = M[w,q]^T into the upper blocks
+  {
+    const int q = wave;
+    v4d Mt[NBT];
 #pragma unroll
-  for (int c = 0; c < 28; ++c) {
-    const int i = rg + 4 * c;
-    Akk[(size_t)i * N + l] = a[c];
-    Pb[i * NB + l] = -a[c];
+    for (int t = 0; t < NBT; ++t) Mt[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int t = 0; t < NBT; ++t)
+      if (t == q) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) Mt[t][c] = Dinv[(q * 16 + lk + 4 * c) * PV_DLD + lr];
+      }
+#pragma unroll
+    for (int w = 1; w < NBT; ++w) {
+      if (w > q) {
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int t = 0; t < w; ++t) {
+          if (t >= q) {
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+              const double av = S[(16 * w + lr) * PV_LD + 16 * t + lk + 4 * ks];  // L[w,t]
+              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Mt[t][ks], acc, 0, 0, 0);
+            }
+          }
+        }
+        v4d res = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const double av = Dinv[(w * 16 + lr) * PV_DLD + lk + 4 * ks];  // inv(L16_w)[lr][k]
+          res = __builtin_amdgcn_mfma_f64_16x16x4f64(av, -acc[ks], res, 0, 0, 0);
+        }
+        Mt[w] = res;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) S[(16 * q + lr) * PV_LD + 16 * w + lk + 4 * c] = res[c];  // U[q,w]
+      }
+    }
+  }
+  __syncthreads();
+  // ---------------- phase 3: P = U U^T, wave a computes P[a, 0..a]; A_kk <- -P (both triangles)
+  {
+    const int a = wave;
+#pragma unroll
+    for (int bb = 0; bb < NBT; ++bb) {
+      if (bb <= a) {
+        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+        for (int t = a; t < NBT; ++t) {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) {
+            const int kk = lk + 4 * ks;
+            // A operand: U[a,t][lr][kk] ; B operand: U[bb,t][col=lr][kk]
+            const double av = (t == a) ? Dinv[(a * 16 + kk) * PV_DLD + lr] : S[(16 * a + lr) * PV_LD + 16 * t + kk];
+            const double bv = (t == bb) ? Dinv[(bb * 16 + kk) * PV_DLD + lr] : S[(16 * bb + lr) * PV_LD + 16 * t + kk];
+            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
+          }
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          Akk[(size_t)(16 * a + lk + 4 * c) * N + 16 * bb + lr] = -acc[c];
+          if (bb != a) Akk[(size_t)(16 * bb + lr) * N + 16 * a + lk + 4 * c] = -acc[c];
+        }
+      }
+    }
+  }
+  // ---------------- phase 4: U (upper) and M = U^T (lower) to global, dense NBxNB row-major
+  double* Ub = Ubuf + (size_t)b * NB * NB;
+  double* Mb = Mbuf + (size_t)b * NB * NB;
+  for (int e = tid; e < NB * NB; e += MM_THREADS) {
+    const int i = e / NB, j = e % NB;
+    const int bi = i >> 4, bj = j >> 4;
+    double u = 0.0, mv = 0.0;
+    if (bi < bj) u = S[i * PV_LD + j];
+    else if (bi == bj) u = Dinv[(bi * 16 + (j & 15)) * PV_DLD + (i & 15)];   // U[i][j] = M16[j][i]
+    if (bj < bi) mv = S[j * PV_LD + i];                                       // M[i][j] = U[j][i]
+    else if (bi == bj) mv = Dinv[(bi * 16 + (i & 15)) * PV_DLD + (j & 15)];
+    Ub[e] = u;
+    Mb[e] = mv;
   }
   if (tid == 0) {
     logdet[b] += ld;
     if (bad) flags[b] = 1;
   }
 }
+#define PIVOT_LDS_BYTES ((NB * PV_LD + 2 * NBT * 16 * PV_DLD) * sizeof(double))
 
 // ------------------------------------------------- shared MFMA tile product
-// acc[t] (16 rows of this wave x 16 cols of tile t) += sum_kk Aop[kk][m] * Bop[kk][nn]
-// over kk in [0, NB).  Aop/Bop are "k-major" sources: element (kk, c) at
-// ptr[kk*ld + c]; if TRANS_B, Bop is row-major instead: element (kk, c) at ptr[c*ld + kk].
+// acc[t] (16 rows of this wave x 16 cols of tile t) += sum_kk Aop[kk][16*wave + .] * Bop[kk][16*t + .]
+// over kk in [0, NB).  Aop/Bop are "k-major" sources: element (kk, c) at ptr[kk*ld + c];
+// if TRANS_A, Aop is row-major instead: element (kk, c) at ptr[c*ld + kk].
 // Staged through LDS in chunks of KC with register prefetch of the next chunk.
+// SKIP: Bop is block-triangular at 16x16 granularity, skip the zero products:
+//   SKIP_UPPER  Bop[kk][c] == 0 unless tile(c) >= chunk(kk)
+//   SKIP_LOWER  Bop[kk][c] == 0 unless tile(c) <= chunk(kk)
+enum { SKIP_NONE = 0, SKIP_UPPER = 1, SKIP_LOWER = 2 };
 struct Stage { double a[4]; double b[4]; };
 
-template <bool TRANS_B>
+template <bool TRANS_A>
 __device__ __forceinline__ void stage_load(Stage& s, const double* __restrict__ Aop, int lda,
                                            const double* __restrict__ Bop, int ldb, int chunk, int tid) {
   const int idx = tid * 4;
-  {
+  if (!TRANS_A) {
     const int kk = idx / NB, c = idx % NB;
     const double* p = Aop + (size_t)(chunk * KC + kk) * lda + c;
 #pragma unroll
     for (int u = 0; u < 4; ++u) s.a[u] = p[u];
+  } else {
+    const int r = idx / KC, kq = idx % KC;
+    const double* p = Aop + (size_t)r * lda + chunk * KC + kq;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) s.a[u] = p[u];
   }
-  if (!TRANS_B) {
+  {
     const int kk = idx / NB, c = idx % NB;
     const double* p = Bop + (size_t)(chunk * KC + kk) * ldb + c;
 #pragma unroll
     for (int u = 0; u < 4; ++u) s.b[u] = p[u];
-  } else {
-    const int r = idx / KC, kq = idx % KC;
-    const double* p = Bop + (size_t)r * ldb + chunk * KC + kq;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) s.b[u] = p[u];
   }
 }
 
-template <bool TRANS_B>
+template <bool TRANS_A>
 __device__ __forceinline__ void stage_store(const Stage& s, double* __restrict__ As, double* __restrict__ Bs, int tid) {
   const int idx = tid * 4;
-  {
+  if (!TRANS_A) {
     const int kk = idx / NB, c = idx % NB;
 #pragma unroll
     for (int u = 0; u < 4; ++u) As[kk * LDS_LD + c + u] = s.a[u];
-  }
-  if (!TRANS_B) {
-    const int kk = idx / NB, c = idx % NB;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) Bs[kk * LDS_LD + c + u] = s.b[u];
   } else {
     const int r = idx / KC, kq = idx % KC;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) Bs[(kq + u) * LDS_LD + r] = s.b[u];
+    for (int u = 0; u < 4; ++u) As[(kq + u) * LDS_LD + r] = s.a[u];
+  }
+  {
+    const int kk = idx / NB, c = idx % NB;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) Bs[kk * LDS_LD + c + u] = s.b[u];
   }
 }
 
+template <int SKIP>
 __device__ __forceinline__ void chunk_mfma(const double* __restrict__ As, const double* __restrict__ Bs,
-                                           v4d acc[NBT], int wave, int lane) {
+                                           v4d acc[NBT], int wave, int lane, int ch) {
   const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int ks = 0; ks < KC / 4; ++ks) {
@@ -310,19 +464,45 @@ __device__ __forceinline__ void chunk_mfma(const double* __restrict__ As, const 
     const double av = As[row + 16 * wave + lr];
 #pragma unroll
     for (int t = 0; t < NBT; ++t) {
+      if (SKIP == SKIP_UPPER && t < ch) continue;
+      if (SKIP == SKIP_LOWER && t > ch) continue;
       const double bv = Bs[row + 16 * t + lr];
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
     }
   }
 }
 
+// store a wave's 16x112 accumulator strip transposed: dst[(16*t + col) * ld + 16*wave + row] = sign*acc
+// (per-wave 16x17 LDS scratch; the staging buffers must be free)
+__device__ __forceinline__ void store_strip_transposed(const v4d acc[NBT], double* __restrict__ dst, size_t ld,
+                                                       double* __restrict__ scratch, int wave, int lane,
+                                                       double sign, double* __restrict__ dst2) {
+  const int lr = lane & 15, lk = lane >> 4;
+  double* tr = scratch + wave * (16 * 17);
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) {
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) tr[(lk + 4 * rr) * 17 + lr] = acc[t][rr];  // [row][col]
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) {
+      const int cl = lk + 4 * rr;  // col local
+      const double v = tr[lr * 17 + cl];   // element (row = lr, col = cl)
+      const size_t off = (size_t)(16 * t + cl) * ld + 16 * wave + lr;
+      dst[off] = sign * v;
+      if (dst2) dst2[off] = -sign * v;
+    }
+    __builtin_amdgcn_wave_barrier();
+  }
+}
+
 // ------------------------------------------------------------------ panel
-// grid.x = (nblk-1) * B.  For row block i != k:
-//   T = A_ik (stored as block (i,k) when i > k, as block (k,i) transposed when i < k)
-//   D[k'][r] = sum_kk P[k'][kk] T[r][kk]   (= (A_ik P)^T)
-//   Wo[kk][i0+r] = T[r][kk] ; Wn[k'][i0+r] = -D ; A_ik <- D^T
-__global__ void __launch_bounds__(MM_THREADS)
-k_panel(double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Pbuf,
+// grid.x = (nblk-1) * B.  For row block i != k, T = A_ik (block (i,k) row-major when i > k,
+// block (k,i) = T^T, i.e. k-major, when i < k):
+//   W = T L^-T = T U :  acc[r][k'] = sum_kk T[r][kk] U[kk][k']   (U upper: SKIP_UPPER)
+//   Wo[k'][i0+r] = W ,  Wn[k'][i0+r] = -W     (k-major panels for the update)
+__global__ void __launch_bounds__(MM_THREADS, 4)
+k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Ubuf,
         double* __restrict__ Wn, double* __restrict__ Wo, int total) {
   __shared__ double lds[2 * KC * LDS_LD];
   double* As = lds; double* Bs = lds + KC * LDS_LD;
@@ -330,99 +510,98 @@ k_panel(double* __restrict__ A, int N, int nblk, int k, const double* __restrict
   const int v = xcd_remap(blockIdx.x, total);
   const int b = v / (nblk - 1);
   int i = v % (nblk - 1); if (i >= k) ++i;
-  double* Ab = A + (size_t)b * N * N;
-  const double* P = Pbuf + (size_t)b * NB * NB;
-  double* Wnb = Wn + (size_t)b * NB * N;
-  double* Wob = Wo + (size_t)b * NB * N;
+  const double* Ab = A + (size_t)b * N * N;
+  const double* U = Ubuf + (size_t)b * NB * NB;
   const int i0 = i * NB, k0 = k * NB;
   const bool below = i > k;
-  // T source: below: row-major [r][kk] at A[(i0+r)*N + k0+kk]; above: k-major [kk][r] at A[(k0+kk)*N + i0+r]
   const double* Tsrc = below ? Ab + (size_t)i0 * N + k0 : Ab + (size_t)k0 * N + i0;
   v4d acc[NBT];
 #pragma unroll
   for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
   Stage st;
-  if (below) stage_load<true>(st, P, NB, Tsrc, N, 0, tid); else stage_load<false>(st, P, NB, Tsrc, N, 0, tid);
+  if (below) stage_load<true>(st, Tsrc, N, U, NB, 0, tid); else stage_load<false>(st, Tsrc, N, U, NB, 0, tid);
   for (int ch = 0; ch < NB / KC; ++ch) {
     __syncthreads();
     if (below) stage_store<true>(st, As, Bs, tid); else stage_store<false>(st, As, Bs, tid);
     __syncthreads();
     if (ch + 1 < NB / KC) {
-      if (below) stage_load<true>(st, P, NB, Tsrc, N, ch + 1, tid); else stage_load<false>(st, P, NB, Tsrc, N, ch + 1, tid);
+      if (below) stage_load<true>(st, Tsrc, N, U, NB, ch + 1, tid); else stage_load<false>(st, Tsrc, N, U, NB, ch + 1, tid);
     }
-    {  // old panel out: Wo[ch*KC + kk][i0 + c..c+3] = Bs[kk][c..]
-      const int idx = tid * 4, kk = idx / NB, c = idx % NB;
-      double* dst = Wob + (size_t)(ch * KC + kk) * N + i0 + c;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) dst[u] = Bs[kk * LDS_LD + c + u];
-    }
-    chunk_mfma(As, Bs, acc, wave, lane);
+    chunk_mfma<SKIP_UPPER>(As, Bs, acc, wave, lane, ch);
   }
-  // D rows k' = 16*wave + (lane>>4) + 4*rr, cols r = 16*t + (lane&15)
-  const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-  for (int t = 0; t < NBT; ++t) {
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) {
-      const int kp = 16 * wave + lk + 4 * rr;
-      Wnb[(size_t)kp * N + i0 + 16 * t + lr] = -acc[t][rr];
-      if (!below) Ab[(size_t)(k0 + kp) * N + i0 + 16 * t + lr] = acc[t][rr];
-    }
-  }
-  if (below) {
-    __syncthreads();  // staging buffers are free now; per-wave 16x17 transpose scratch
-    double* tr = lds + wave * (16 * 17);
-#pragma unroll
-    for (int t = 0; t < NBT; ++t) {
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) tr[(lk + 4 * rr) * 17 + lr] = acc[t][rr];  // [k' local][r local]
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int rr = 0; rr < 4; ++rr) {
-        const int rl = lk + 4 * rr;  // r local
-        Ab[(size_t)(i0 + 16 * t + rl) * N + k0 + 16 * wave + lr] = tr[lr * 17 + rl];
-      }
-      __builtin_amdgcn_wave_barrier();
-    }
-  }
+  __syncthreads();
+  // acc[t][rr] = W[r = 16*wave + lk + 4rr][k' = 16t + lr]  ->  Wo[k'][i0 + r], Wn = -W
+  store_strip_transposed(acc, Wo + (size_t)b * NB * N + i0, (size_t)N, lds, wave, lane, 1.0,
+                         Wn + (size_t)b * NB * N + i0);
 }
 
 // ----------------------------------------------------------------- update
-// grid.x = ntri(nblk-1) * B.  A_IJ += Wn_I^T-product: A[I0+m][J0+nn] += sum_kk Wn[kk][I0+m] Wo[kk][J0+nn]
-__global__ void __launch_bounds__(MM_THREADS)
+// grid.x = (ntri(nblk-1) + nblk-1) * B.  Two kinds of 112x112 tile products:
+//   trailing tile (I,J), I >= J, I,J != k:   A_IJ -= W_I W_J^T      (Aop = Wn_I, Bop = Wo_J)
+//   pivot-column tile I != k:                A_Ik  = W_I L^-1 = W_I M (Aop = Wo_I, Bop = M lower: SKIP_LOWER)
+//     stored row-major into block (I,k) when I > k, transposed into block (k,I) when I < k.
+__global__ void __launch_bounds__(MM_THREADS, 4)
 k_update(double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Wn,
-         const double* __restrict__ Wo, int ntri1, int total) {
+         const double* __restrict__ Wo, const double* __restrict__ Mbuf, int ntri1, int total) {
   __shared__ double lds[2 * KC * LDS_LD];
   double* As = lds; double* Bs = lds + KC * LDS_LD;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int v = xcd_remap(blockIdx.x, total);
-  const int b = v / ntri1, t0 = v % ntri1;
-  int I, J; tri_decode(t0, I, J);
-  if (I >= k) ++I;
-  if (J >= k) ++J;
+  const int per = ntri1 + nblk - 1;
+  const int b = v / per, t0 = v % per;
   double* Ab = A + (size_t)b * N * N;
-  const double* Aop = Wn + (size_t)b * NB * N + I * NB;
-  const double* Bop = Wo + (size_t)b * NB * N + J * NB;
   const int lr = lane & 15, lk = lane >> 4;
-  double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + J * NB + lr;
-  Stage st;
-  stage_load<false>(st, Aop, N, Bop, N, 0, tid);
   v4d acc[NBT];
+  Stage st;
+  if (t0 < ntri1) {
+    int I, J; tri_decode(t0, I, J);
+    if (I >= k) ++I;
+    if (J >= k) ++J;
+    const double* Aop = Wn + (size_t)b * NB * N + I * NB;
+    const double* Bop = Wo + (size_t)b * NB * N + J * NB;
+    double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + J * NB + lr;
+    stage_load<false>(st, Aop, N, Bop, N, 0, tid);
 #pragma unroll
-  for (int t = 0; t < NBT; ++t)
+    for (int t = 0; t < NBT; ++t)
 #pragma unroll
-    for (int rr = 0; rr < 4; ++rr) acc[t][rr] = Ct[(size_t)(4 * rr) * N + 16 * t];
-  for (int ch = 0; ch < NB / KC; ++ch) {
-    __syncthreads();
-    stage_store<false>(st, As, Bs, tid);
-    __syncthreads();
-    if (ch + 1 < NB / KC) stage_load<false>(st, Aop, N, Bop, N, ch + 1, tid);
-    chunk_mfma(As, Bs, acc, wave, lane);
+      for (int rr = 0; rr < 4; ++rr) acc[t][rr] = Ct[(size_t)(4 * rr) * N + 16 * t];
+    for (int ch = 0; ch < NB / KC; ++ch) {
+      __syncthreads();
+      stage_store<false>(st, As, Bs, tid);
+      __syncthreads();
+      if (ch + 1 < NB / KC) stage_load<false>(st, Aop, N, Bop, N, ch + 1, tid);
+      chunk_mfma<SKIP_NONE>(As, Bs, acc, wave, lane, ch);
+    }
+#pragma unroll
+    for (int t = 0; t < NBT; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+  } else {
+    int I = t0 - ntri1; if (I >= k) ++I;
+    const double* Aop = Wo + (size_t)b * NB * N + I * NB;
+    const double* Bop = Mbuf + (size_t)b * NB * NB;
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    stage_load<false>(st, Aop, N, Bop, NB, 0, tid);
+    for (int ch = 0; ch < NB / KC; ++ch) {
+      __syncthreads();
+      stage_store<false>(st, As, Bs, tid);
+      __syncthreads();
+      if (ch + 1 < NB / KC) stage_load<false>(st, Aop, N, Bop, NB, ch + 1, tid);
+      chunk_mfma<SKIP_LOWER>(As, Bs, acc, wave, lane, ch);
+    }
+    // acc[t][rr] = C[m = 16*wave + lk + 4rr][nn = 16t + lr]
+    if (I > k) {
+      double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + k * NB + lr;
+#pragma unroll
+      for (int t = 0; t < NBT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+    } else {
+      __syncthreads();
+      store_strip_transposed(acc, Ab + (size_t)(k * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr);
+    }
   }
-#pragma unroll
-  for (int t = 0; t < NBT; ++t)
-#pragma unroll
-    for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
 }
 
 // ------------------------------------------------------------------ grad1

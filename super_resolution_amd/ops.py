@@ -225,3 +225,22 @@ def axpy(a, b, alpha):
     _lib.check(lib.gpsr_axpy(_p(a, torch.float64), _p(b, torch.float64), float(alpha), _p(out), a.numel(), _stream()),
                "gpsr_axpy")
     return out
+
+
+# ------------------------------------------------------------ kernel timing
+PROF_TAGS = ("update", "panel", "pivot", "build", "grad1", "grad2", "predict")
+
+
+def profile_begin(max_records=65536):
+    _lib.check(_lib.load().gpsr_profile_begin(int(max_records)), "gpsr_profile_begin")
+
+
+def profile_end():
+    """-> {tag: (launch_count, total_ms)} measured with HIP events on the launch stream."""
+    import ctypes
+    n = len(PROF_TAGS)
+    counts = (ctypes.c_int32 * n)()
+    ms = (ctypes.c_double * n)()
+    _lib.check(_lib.load().gpsr_profile_end(ctypes.cast(counts, ctypes.c_void_p), ctypes.cast(ms, ctypes.c_void_p)),
+               "gpsr_profile_end")
+    return {t: (int(counts[i]), float(ms[i])) for i, t in enumerate(PROF_TAGS)}
