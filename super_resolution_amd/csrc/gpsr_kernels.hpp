@@ -218,6 +218,7 @@ __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, d
   const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int c = 0; c < 4; ++c) m[c] = (lk + 4 * c == lr) ? 1.0 : 0.0;
+  double prod = 1.0;
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int jr = j & 3, jc = j >> 2;
@@ -228,8 +229,8 @@ __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, d
 #pragma unroll
     for (int c = 0; c < 4; ++c) ci[c] = __shfl(a[c], j + 16 * lk);  // D[lk+4c][j] (column j)
     if (!(pv > 0.0)) *bad = 1;
-    *ld += log(pv);
-    const double rinv = 1.0 / sqrt(pv);
+    prod *= pv;                     // 16 pivots in [1e-4, 1e3]: no over/underflow; one log per tile
+    const double rinv = rsqrt(pv);
     const double clr = cl * rinv;   // L[lr][j]
     const double mjs = mj * rinv;   // row j of M, final
 #pragma unroll
@@ -249,6 +250,7 @@ __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, d
 #pragma unroll
   for (int c = 0; c < 4; ++c)
     if (lr > lk + 4 * c) a[c] = 0.0;
+  *ld += log(prod);
 }
 
 __global__ void __launch_bounds__(MM_THREADS)

@@ -1,0 +1,237 @@
+"""CPU tests (-m "not gpu") of the product's host side: the C-ABI library loads and
+exports every symbol include/gpsr.h declares (no compute calls), the drop-in
+host logic (PatchHandler geometry, kernel registry, resize tables, sharding), and
+the N>1 exchange on world_size-2 gloo."""
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ----------------------------------------------------------------- C ABI
+def _declared_symbols():
+    text = open(os.path.join(ROOT, "include", "gpsr.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(gpsr_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    from super_resolution_amd import _lib
+    assert os.path.exists(_lib.LIB_PATH), "run __graft_entry__.build() first"
+    lib = _lib.load()
+    syms = _declared_symbols()
+    assert len(syms) >= 25
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/gpsr.h but not exported"
+        assert s in _lib.SIGNATURES, f"{s} has no ctypes signature"
+    assert set(_lib.SIGNATURES) == set(syms)
+    assert lib.gpsr_version().decode() == "gpsr 0.1 gfx950"
+    assert [lib.gpsr_padded_n(n) for n in (1, 100, 112, 113, 324, 784, 1024)] == [112, 112, 112, 224, 336, 784, 1120]
+    assert lib.gpsr_fit_workspace_bytes(0, 324, 8) == 0
+    assert lib.gpsr_fit_workspace_bytes(2, 784, 8) > 2 * 784 * 784 * 8
+
+
+def test_library_is_gfx950_code_object():
+    from super_resolution_amd import _lib
+    out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH],
+                         capture_output=True, text=True)
+    if out.returncode == 0:
+        assert "gfx950" in out.stdout
+
+
+def test_ops_refuse_cpu_tensors():
+    from super_resolution_amd import _lib, ops
+    with pytest.raises(_lib.GpsrError):
+        ops.covariance(torch.zeros(1, 4, 8, dtype=torch.float64), 0, torch.zeros(1, 4))
+
+
+# ----------------------------------------------------------------- PatchHandler / kernels drop-in surface
+def test_patch_handler_geometry_matches_reference(golden_dir):
+    from super_resolution_amd.image_patches import PatchHandler, PatchInterpolationMode
+    g = np.load(f"{golden_dir}/patches_locations.npz")
+    for k in g.files:
+        parts = k.split("_")
+        H, W, p = map(int, parts[:3])
+        sp = float(parts[3]) if len(parts) > 3 else 0.9
+        h = PatchHandler([np.zeros((H, W))], base_patch_size=p, stride_percentage=sp)
+        assert np.array_equal(np.array(h.patch_locations), g[k]), k
+        assert h.stride == int((p - 2) * sp) and h.scale_factors == [1]
+    d = np.load(f"{golden_dir}/patches_iter_combine.npz")
+    for tag in ("s2", "s3", "s2dup"):
+        H, W, p, s = [int(v) for v in d[tag + "_meta"]]
+        h = PatchHandler([d[tag + "_a"], d[tag + "_b"], d[tag + "_c"]], base_patch_size=p)
+        assert h.scale_factors == [1, 1, s]
+        trip = list(h)
+        assert len(trip) == len(h.patch_locations)
+        assert np.array_equal(np.stack([t[0] for t in trip]), d[tag + "_pa"])
+        assert np.array_equal(np.stack([t[2] for t in trip]), d[tag + "_pc"])
+        trip[0][0][:] = -1                     # patches are copies (image_patches.py:102)
+        assert d[tag + "_a"].min() >= 0
+    assert PatchInterpolationMode.AVERAGE.value == 0 and PatchInterpolationMode.BILINEAR.value == 1
+    with pytest.raises(AssertionError):
+        PatchHandler([np.zeros((10, 30))], base_patch_size=20)
+
+
+def test_kernel_registry_names_and_ids():
+    from super_resolution_amd import kernels as K, ops
+    names = [K.get_kernel_name(k) for k in (K.rbf_kernel, K.matern52_kernel, K.matern32_kernel, K.exponential_kernel,
+                                            K.linear_kernel, K.periodic_kernel, K.spectral_mixture_kernel)]
+    assert names == ["RBF", "matern52", "matern32", "matern12", "linear", "periodic", "spectral_mixture"]
+    assert K.get_kernel_name(K.AdditiveKernel(K.rbf_kernel, K.linear_kernel)) == "add(RBF,linear)"
+    assert K.get_kernel_name(K.ProductKernel(K.rbf_kernel, K.matern32_kernel)) == "prod(RBF,matern32)"
+    assert [K.kernel_id_of(k) for k in (K.rbf_kernel, K.exponential_kernel, K.matern32_kernel, K.matern52_kernel,
+                                        K.linear_kernel)] == [ops.RBF, ops.MATERN12, ops.MATERN32, ops.MATERN52, ops.LINEAR]
+    with pytest.raises(NotImplementedError):
+        K.kernel_id_of(K.periodic_kernel)
+    with pytest.raises(Exception):
+        K.get_kernel_name(object())
+
+
+def test_gprsr_module_surface():
+    import gprsr, kernels, image_patches, main  # the top-level drop-in modules  # noqa: F401
+    for name in ("GPRSR", "ColorSpace", "SRF", "IMAGE_NUMS", "DO_TIMING", "USED_COLOR_SPACE", "USED_KERNEL",
+                 "USE_ALL_PIXELS_FOR_TRAINING", "LEARNING_RATE", "STRIDE_PERCENTAGE", "PATCH_INTERPOLATION",
+                 "extract_patch", "extract_neighbors"):
+        assert hasattr(gprsr, name), name
+    assert gprsr.LEARNING_RATE == 0.1 and gprsr.STRIDE_PERCENTAGE == 0.9 and gprsr.SRF == 2
+    assert [c.name for c in gprsr.ColorSpace] == ["BGR", "YUV", "GRAYSCALE"]
+    img = np.arange(25.).reshape(5, 5)
+    assert gprsr.extract_neighbors(img, 2, 2) == [17.0, 7.0, 13.0, 11.0, 18.0, 6.0, 16.0, 8.0]
+    g = gprsr.GPRSR(3)
+    assert g.used_kernel is kernels.matern52_kernel and g.color_mode == gprsr.ColorSpace.YUV
+    for m in ("apply", "apply_for_channel", "upsample", "blur_downsample", "deblur", "predict_pixels"):
+        assert callable(getattr(g, m))
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError):          # no silent CPU fallback
+            g.apply_for_channel(np.zeros((40, 40), dtype=np.uint8))
+
+
+def test_main_options_parse():
+    import main
+    a = main.parse_args(["--srf", "3", "--kernel", "matern32", "--color-space", "yuv", "--images", "2-4",
+                         "--stride-percentage", "0.8", "--patch-interpolation", "bilinear", "--grid-training",
+                         "--warm-start", "chain", "--no-timing", "--dataset-dir", "/tmp/x"])
+    assert a.srf == 3 and a.kernel == "matern32" and a.color_space == "yuv" and a.images == "2-4"
+    assert a.stride_percentage == 0.8 and a.patch_interpolation == "bilinear" and a.grid_training
+    assert main.image_numbers("2-4") == [2, 3, 4] and main.image_numbers("1,3,14") == [1, 3, 14]
+    assert main.output_path("Set14", 3, 7, "matern52", True) == "Set14/image_SRF_3/img_007_SRF_3_GPR_matern52_gray.png"
+    assert main.output_path("Set14", 2, 1, "RBF", False) == "Set14/image_SRF_2/img_001_SRF_2_GPR_RBF.png"
+
+
+# ----------------------------------------------------------------- resize tables vs the oracle's scalar restatement
+@pytest.mark.parametrize("n_src,inv_scale", [(37, 2.0), (53, 3.0), (40, 4.0), (90, 1 / 3), (75, 0.4)])
+def test_resize_tables_match_oracle(n_src, inv_scale):
+    from oracle import cvops
+    from super_resolution_amd import imgproc
+    n_dst = imgproc.cv_round(n_src * inv_scale)
+    i1, w1 = imgproc._axis_tables(n_dst, n_src, float(inv_scale), "cubic")
+    i2, w2 = cvops._cubic_tables(n_dst, n_src, inv_scale)
+    assert np.array_equal(i1, i2) and np.array_equal(w1, w2.astype(np.float64))
+    i1, w1 = imgproc._axis_tables(n_dst, n_src, float(inv_scale), "linear")
+    i2, w2 = cvops._linear_tables(n_dst, n_src, inv_scale)
+    assert np.array_equal(i1, i2) and np.array_equal(w1, w2.astype(np.float64))
+    assert np.array_equal(imgproc.gaussian_kernel(5, 0), cvops.gaussian_kernel(5, 0))
+    assert np.array_equal(imgproc.gaussian_kernel(3, 1), cvops.gaussian_kernel(3, 1))
+
+
+# ----------------------------------------------------------------- sharding
+def test_shard_ranges_partition_the_patch_list():
+    from super_resolution_amd.dist import shard_range
+    for B in (1, 7, 8, 633, 32400):
+        for world in (1, 2, 3, 8):
+            cuts = [shard_range(B, r, world) for r in range(world)]
+            assert cuts[0][0] == 0 and cuts[-1][1] == B
+            assert all(cuts[i][1] == cuts[i + 1][0] for i in range(world - 1))
+            sizes = [hi - lo for lo, hi in cuts]
+            assert max(sizes) - min(sizes) <= 1
+
+
+_WORKER = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from super_resolution_amd.dist import shard_range, all_gather_rows, init_from_env
+rank, world, _ = init_from_env("gloo")
+B = 11
+full = torch.arange(B * 3, dtype=torch.float64).reshape(B, 3) * 1.5
+lo, hi = shard_range(B, rank, world)
+local = full[lo:hi].clone() + 0.0
+out = all_gather_rows(local, B, world)
+flags = all_gather_rows(torch.arange(lo, hi, dtype=torch.int32), B, world)
+assert torch.equal(out, full), (rank, out)
+assert torch.equal(flags, torch.arange(B, dtype=torch.int32))
+dist.barrier()
+sys.stdout.write("rank%dok\n" % rank); sys.stdout.flush()
+'''
+
+
+def test_all_gather_rows_world2_gloo(tmp_path):
+    script = tmp_path / "w.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29611", str(script)],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank0ok" in r.stdout and "rank1ok" in r.stdout
+
+
+_WORKER_ENGINE = r'''
+import os, sys, numpy as np, torch, torch.distributed as dist
+sys.path.insert(0, {root!r})
+from super_resolution_amd import engine, ops, dist as gdist
+rank, world, _ = gdist.init_from_env("gloo")
+
+# Stand-ins for the device ops (no GPU here): gather = real patch features in numpy,
+# the "GP" = a deterministic function of each patch, combine = oracle recombination.
+from oracle import patches as P
+def fake_gather(tin, ttg, tst, s, p, locs, tidx):
+    tin, ttg, tst = tin.numpy(), ttg.numpy(), tst.numpy()
+    X = np.stack([P.features(P.extract(tin, l, p, 1)) for l in locs.numpy()])
+    y = np.stack([P.targets(P.extract(ttg, l, p, 1)) for l in locs.numpy()])
+    Xs = np.stack([P.features(P.extract(tst, l, p, s)) for l in locs.numpy()])
+    return torch.tensor(X), torch.tensor(y), torch.tensor(Xs)
+def fake_combine(pred, tst, H, W, s, p, rows, cols, mode, clip=True):
+    locs = [(int(r), int(c)) for r in rows for c in cols]
+    ups = []
+    for k, l in enumerate(locs):
+        q = P.extract(tst.numpy(), l, p, s); q[1:-1, 1:-1] = pred[k].numpy().reshape(p * s - 2, p * s - 2); ups.append(q)
+    return torch.tensor(np.clip(P.combine(ups, locs, (H, W), p, mode), 0, 1))
+ops.gather, ops.combine = fake_gather, fake_combine
+class FakeGP:
+    def fit_predict(self, X, y, Xs, chain_kernel=None):
+        pred = Xs.mean(-1) * 0.5 + y.mean(-1, keepdim=True) * 0.5
+        raw = torch.stack([y.mean(-1), y.std(-1), X.mean((1, 2)), X.amax((1, 2))], 1).float()
+        return pred, raw, torch.zeros(X.shape[0], dtype=torch.int32)
+rng = np.random.default_rng(0)
+jobs = []
+for (H, W) in [(47, 53), (52, 36)]:
+    a, b, c = rng.random((H, W)), rng.random((H, W)), rng.random((2 * H, 2 * W))
+    jobs.append((torch.tensor(a), torch.tensor(b), torch.tensor(c)))
+st = engine.FitStats()
+outs = engine.predict_pixels_batch(jobs, 2, 20, FakeGP(), stats=st, shard=(rank, world))
+ref = engine.predict_pixels_batch(jobs, 2, 20, FakeGP(), shard=None) if rank == 0 else None
+if rank == 0:
+    for o, r in zip(outs, ref):
+        assert torch.equal(o, r)
+    assert st.raw[0].shape == (24, 4)
+dist.barrier()
+sys.stdout.write("rank%dok\n" % rank); sys.stdout.flush()
+'''
+
+
+def test_sharded_predict_pixels_equals_unsharded_world2_gloo(tmp_path):
+    """The N>1 path: each rank fits its slice of the patch list, all-gather, identical recombination."""
+    script = tmp_path / "e.py"
+    script.write_text(_WORKER_ENGINE.format(root=ROOT))
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29612", str(script)],
+                       capture_output=True, text=True, env=env, timeout=240)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "rank0ok" in r.stdout and "rank1ok" in r.stdout

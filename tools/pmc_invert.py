@@ -1,0 +1,19 @@
+"""Micro-workload for rocprofv3 --pmc passes: one batched inversion (7 pivot steps of
+pivot / panel / update) of B SPD matrices of order N, as in one Adam iteration."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from super_resolution_amd import ops
+
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 633
+N = int(sys.argv[2]) if len(sys.argv) > 2 else 784
+reps = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+dev = torch.device("cuda:0")
+g = torch.Generator(device=dev); g.manual_seed(0)
+Q = torch.randn((B, N, 64), dtype=torch.float64, device=dev, generator=g)
+A0 = Q @ Q.transpose(1, 2) / 64 + 0.5 * torch.eye(N, dtype=torch.float64, device=dev)
+for _ in range(reps):
+    A = A0.clone()
+    logdet, flags = ops.invert_(A)
+torch.cuda.synchronize()
+print("flags", int(flags.sum()), "logdet0", float(logdet[0]))
