@@ -1,0 +1,97 @@
+"""GPU parity tests of the AGPR path (BASELINE config 5) through the reference-shaped
+API, against the oracle and against the reference's committed checkpoints."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import agpr as oagpr, gp as ogp
+from test_gpu_kernels import natural_image, to_dev
+
+
+def _write_checkpoint(tmp, golden_dir, name):
+    f = np.load(f"{golden_dir}/agpr_{name.replace('/', '_')}.npz")
+    folder = os.path.join(tmp, "checkpoints", name)
+    os.makedirs(folder)
+    torch.save(torch.tensor(f["train_x"]), os.path.join(folder, "train_x.pt"))
+    torch.save(torch.tensor(f["train_y"]), os.path.join(folder, "train_y.pt"))
+    r = f["raw"].astype(np.float32)
+    sd = {"likelihood.noise_covar.raw_noise": torch.tensor([r[0]]),
+          "likelihood.noise_covar.raw_noise_constraint.lower_bound": torch.tensor(1e-4),
+          "likelihood.noise_covar.raw_noise_constraint.upper_bound": torch.tensor(float("inf")),
+          "mean_module.raw_constant": torch.tensor(r[1]),
+          "covar_module.raw_outputscale": torch.tensor(r[2]),
+          "covar_module.base_kernel.raw_variance": torch.tensor([[r[3]]]),
+          "covar_module.base_kernel.raw_variance_constraint.lower_bound": torch.tensor(0.0),
+          "covar_module.base_kernel.raw_variance_constraint.upper_bound": torch.tensor(float("inf")),
+          "covar_module.raw_outputscale_constraint.lower_bound": torch.tensor(0.0),
+          "covar_module.raw_outputscale_constraint.upper_bound": torch.tensor(float("inf"))}
+    torch.save(sd, os.path.join(folder, "model.pt"))
+    assert sorted(sd) == sorted(str(k) for k in f["state_dict_keys"])   # the reference's key set
+    return f
+
+
+@pytest.mark.parametrize("name,srf", [("BSD100/SRF_2", 2), ("BSD100/SRF_3", 3)])
+def test_agpr_fit_reproduces_reference_checkpoint(golden_dir, name, srf):
+    """100 Adam steps of the HIP fit on the checkpoint's train_x/train_y must land on the
+    reference's model.pt (produced by real GPyTorch): the known-answer test of the fit path."""
+    from super_resolution_amd import kernels as K
+    f = np.load(f"{golden_dir}/agpr_{name.replace('/', '_')}.npz")
+    K.linear_kernel.reset()
+    m = K.GeneralModel(K.linear_kernel, f["train_x"], f["train_y"])
+    m.fit(iters=100, lr=0.1)
+    K.linear_kernel.reset()
+    got = m.raw[0].cpu().numpy()
+    want = f["raw"]
+    assert abs(got[0] - want[0]) < 1e-4 and abs(got[1] - want[1]) < 1e-5
+    assert abs(got[2] - want[2]) < 1e-4 and abs(got[3] - want[3]) < 1e-4
+    sd = m.state_dict()
+    assert sorted(sd) == sorted(str(k) for k in f["state_dict_keys"])
+    assert sd["covar_module.base_kernel.raw_variance"].shape == (1, 1)
+    assert sd["likelihood.noise_covar.raw_noise"].shape == (1,) and sd["mean_module.raw_constant"].shape == ()
+
+
+@pytest.mark.parametrize("name,srf", [("BSD100/SRF_2", 2), ("BSD100/SRF_3", 3)])
+def test_agpr_upscale_channel_vs_oracle(tmp_path, golden_dir, name, srf):
+    from super_resolution_amd import agpr
+    f = _write_checkpoint(str(tmp_path), golden_dir, name)
+    agpr.BASE_DIR, agpr.SRF, agpr.DATASET = str(tmp_path), srf, agpr.TrainingDataset.BSD100
+    a = agpr.AGPRSuperResolution(srf, use_existing_model=True)
+    lr = np.rint(natural_image(31, 37, 5) * 255).astype(np.uint8)
+    got = a.upscale_channel(lr)
+    h = ogp.Hypers(*f["raw"].astype(np.float32))
+    want = oagpr.upscale_channel(lr, srf, h, f["train_x"], f["train_y"], global_srf=srf)
+    assert got.shape == want.shape == (31 * srf, 37 * srf)
+    assert np.abs(got - want).max() < 1e-6 * 255          # float64 path, << 1/255 of a grey level
+    # the quirk: downscale() divides by the module-global SRF, not self.srf (agpr.py:246)
+    agpr.COLOR_SPACE = agpr.ColorSpace.YCRCB
+    bgr = np.stack([lr, np.clip(lr.astype(int) + 10, 0, 255).astype(np.uint8), 255 - lr], -1)
+    out = a.upscale(bgr)
+    ref = oagpr.upscale(bgr, srf, h, f["train_x"], f["train_y"], global_srf=srf)
+    assert out.shape == ref.shape and out.dtype == np.uint8
+    assert np.abs(out.astype(int) - ref.astype(int)).max() <= 2
+    agpr.BASE_DIR, agpr.SRF = ".", 2
+
+
+def test_agpr_filter_equals_per_pixel_gp_mean(golden_dir):
+    """The 49-tap filter IS the GP posterior mean of every 7x7 window (agpr.py:176)."""
+    from super_resolution_amd import kernels as K, ops
+    f = np.load(f"{golden_dir}/agpr_BSD100_SRF_2.npz")
+    m = K.GeneralModel(K.linear_kernel, f["train_x"], f["train_y"])
+    m.load_state_dict({"likelihood.noise_covar.raw_noise": torch.tensor([f["raw"][0]]),
+                       "mean_module.raw_constant": torch.tensor(f["raw"][1]),
+                       "covar_module.raw_outputscale": torch.tensor(f["raw"][2]),
+                       "covar_module.base_kernel.raw_variance": torch.tensor([[f["raw"][3]]])})
+    alpha = m.ensure_alpha()
+    w = ops.agpr_weights(m.train_x, alpha[0], m.raw[0].contiguous())
+    img = natural_image(20, 23, 1)
+    out = ops.agpr_filter(to_dev(img), 7, w, m.raw[0].contiguous()).cpu().numpy()
+    win = np.lib.stride_tricks.sliding_window_view(img, (7, 7)).reshape(-1, 49)
+    h = ogp.Hypers(*f["raw"].astype(np.float32))
+    mean, _ = ogp.predictive_mean(h, torch.tensor(f["train_x"]), torch.tensor(f["train_y"]),
+                                  torch.tensor(np.ascontiguousarray(win)).float().double(), ogp.LINEAR)
+    assert np.abs(out[3:-3, 3:-3].reshape(-1) - mean.numpy()).max() < 1e-8
+    assert np.array_equal(out[:3], img[:3]) and np.array_equal(out[:, -3:], img[:, -3:])
