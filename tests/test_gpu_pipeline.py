@@ -174,3 +174,38 @@ def test_set14_x3_matern52_parity(golden_dir):
         dp.append(p_got - p_want); ds.append(s_got - s_want)
     assert abs(np.mean(dp)) <= 0.01 and abs(np.mean(ds)) <= 0.001
     assert all(int(f.sum()) == 0 for f in g.stats.flags)
+
+
+def test_set14_x3_final_hypers_close_to_oracle(golden_dir):
+    """The committed oracle run also recorded the raw hyper-parameters after 50 Adam steps
+    (per image, per phase).  float32 Adam trajectories are not bit-comparable; most patches
+    must still end within 1e-2 of the oracle and none may be wildly off."""
+    from super_resolution_amd.gprsr import GPRSR, ColorSpace
+    from super_resolution_amd import kernels as K
+    data = _set14(golden_dir)[:3]
+    hyp = np.load(os.path.join(golden_dir, "set14_x3", "hypers_m52.npz"))
+    for i, lr, _, _ in data:
+        g = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE)
+        g.apply_for_channel(lr)
+        for phase, key in enumerate([f"p1_{i:03d}", f"p2_{i:03d}"]):
+            got, want = g.stats.raw[phase].cpu().numpy(), hyp[key]
+            assert got.shape == want.shape
+            err = np.abs(got - want).max(1)
+            assert np.median(err) < 1e-3 and (err < 1e-2).mean() > 0.95 and err.max() < 0.5, (i, phase, err.max())
+
+
+def test_loose_pin_against_the_references_own_output(golden_dir):
+    """img_001_SRF_3_GPR_matern52.png is an output image the reference's authors committed
+    (unknown settings, probably a chained multi-image run): the closest thing to a golden
+    vector of the whole pipeline incl. the OpenCV stages.  Loose bars only."""
+    from PIL import Image
+    from super_resolution_amd.gprsr import GPRSR, ColorSpace
+    from super_resolution_amd import kernels as K
+    d = os.path.join(golden_dir, "set14_x3")
+    lr, hr = np.array(Image.open(f"{d}/lr_001.png")), np.array(Image.open(f"{d}/hr_001.png"))
+    ref = np.array(Image.open(f"{d}/refout_m52_001.png"))
+    got = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE).apply_for_channel(lr)
+    assert got.shape == ref.shape
+    assert cvops.psnr(ref, got) > 45.0                       # measured 46.8 dB between the two outputs
+    c = 3
+    assert abs(cvops.psnr(hr[c:-c, c:-c], got[c:-c, c:-c]) - cvops.psnr(hr[c:-c, c:-c], ref[c:-c, c:-c])) < 0.03
