@@ -542,11 +542,68 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
 //   trailing tile (I,J), I >= J, I,J != k:   A_IJ -= W_I W_J^T      (Aop = Wn_I, Bop = Wo_J)
 //   pivot-column tile I != k:                A_Ik  = W_I L^-1 = W_I M (Aop = Wo_I, Bop = M lower: SKIP_LOWER)
 //     stored row-major into block (I,k) when I > k, transposed into block (k,I) when I < k.
+// The 16-deep operand chunks go global -> LDS directly (global_load_lds_dwordx4: no VGPR
+// staging, no LDS store pass), double-buffered, one barrier per chunk (9 % faster than
+// the register-staged loop the panel kernel still uses for its transposed operand).  LDS image of a chunk = [16][112] doubles, unpadded (the DMA writes
+// wave-uniform base + lane*16 B, so the image must be lane-linear); the MFMA operand reads
+// (16 consecutive doubles per 16-lane group, rows 896 B apart) are bank-conflict free.
+#define DMA_CHUNK (KC * NB)  // doubles per operand chunk
+
+__device__ __forceinline__ void dma_chunk(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop,
+                                          int ldb, int chunk, double* __restrict__ bufA, double* __restrict__ bufB,
+                                          int wave, int lane) {
+  // 14 KiB per operand = 14 wave-instructions of 1 KiB; wave w issues pieces 2w and 2w+1
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int piece = 2 * wave + u;
+    const int e = piece * 128 + lane * 2;
+    const int kk = e / NB, c = e % NB;
+    const double* ga = Aop + (size_t)(chunk * KC + kk) * lda + c;
+    const double* gb = Bop + (size_t)(chunk * KC + kk) * ldb + c;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                     (__attribute__((address_space(3))) void*)(bufA + piece * 128), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+                                     (__attribute__((address_space(3))) void*)(bufB + piece * 128), 16, 0, 0);
+  }
+}
+
+template <int SKIP>
+__device__ __forceinline__ void chunk_mfma_dma(const double* __restrict__ As, const double* __restrict__ Bs,
+                                               v4d acc[NBT], int wave, int lane, int ch) {
+  const int lr = lane & 15, lk = lane >> 4;
+#pragma unroll
+  for (int ks = 0; ks < KC / 4; ++ks) {
+    const int row = (ks * 4 + lk) * NB;
+    const double av = As[row + 16 * wave + lr];
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) {
+      if (SKIP == SKIP_LOWER && t > ch) continue;
+      const double bv = Bs[row + 16 * t + lr];
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+    }
+  }
+}
+
+template <int SKIP>
+__device__ __forceinline__ void tile_product_dma(const double* __restrict__ Aop, int lda,
+                                                 const double* __restrict__ Bop, int ldb, double* __restrict__ lds,
+                                                 v4d acc[NBT], int wave, int lane) {
+  // lds: [2 buffers][A chunk | B chunk]
+  dma_chunk(Aop, lda, Bop, ldb, 0, lds, lds + DMA_CHUNK, wave, lane);
+  for (int ch = 0; ch < NB / KC; ++ch) {
+    double* cur = lds + (ch & 1) * 2 * DMA_CHUNK;
+    double* nxt = lds + ((ch + 1) & 1) * 2 * DMA_CHUNK;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk ch have landed
+    __syncthreads();                                   // everyone's have; everyone is done reading `nxt`
+    if (ch + 1 < NB / KC) dma_chunk(Aop, lda, Bop, ldb, ch + 1, nxt, nxt + DMA_CHUNK, wave, lane);
+    chunk_mfma_dma<SKIP>(cur, cur + DMA_CHUNK, acc, wave, lane, ch);
+  }
+}
+
 __global__ void __launch_bounds__(MM_THREADS, 4)
 k_update(double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Wn,
-         const double* __restrict__ Wo, const double* __restrict__ Mbuf, int ntri1, int total) {
-  __shared__ double lds[2 * KC * LDS_LD];
-  double* As = lds; double* Bs = lds + KC * LDS_LD;
+             const double* __restrict__ Wo, const double* __restrict__ Mbuf, int ntri1, int total) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int v = xcd_remap(blockIdx.x, total);
   const int per = ntri1 + nblk - 1;
@@ -554,7 +611,6 @@ k_update(double* __restrict__ A, int N, int nblk, int k, const double* __restric
   double* Ab = A + (size_t)b * N * N;
   const int lr = lane & 15, lk = lane >> 4;
   v4d acc[NBT];
-  Stage st;
   if (t0 < ntri1) {
     int I, J; tri_decode(t0, I, J);
     if (I >= k) ++I;
@@ -562,18 +618,11 @@ k_update(double* __restrict__ A, int N, int nblk, int k, const double* __restric
     const double* Aop = Wn + (size_t)b * NB * N + I * NB;
     const double* Bop = Wo + (size_t)b * NB * N + J * NB;
     double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + J * NB + lr;
-    stage_load<false>(st, Aop, N, Bop, N, 0, tid);
 #pragma unroll
     for (int t = 0; t < NBT; ++t)
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) acc[t][rr] = Ct[(size_t)(4 * rr) * N + 16 * t];
-    for (int ch = 0; ch < NB / KC; ++ch) {
-      __syncthreads();
-      stage_store<false>(st, As, Bs, tid);
-      __syncthreads();
-      if (ch + 1 < NB / KC) stage_load<false>(st, Aop, N, Bop, N, ch + 1, tid);
-      chunk_mfma<SKIP_NONE>(As, Bs, acc, wave, lane, ch);
-    }
+    tile_product_dma<SKIP_NONE>(Aop, N, Bop, N, lds, acc, wave, lane);
 #pragma unroll
     for (int t = 0; t < NBT; ++t)
 #pragma unroll
@@ -584,15 +633,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k, const double* __restric
     const double* Bop = Mbuf + (size_t)b * NB * NB;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    stage_load<false>(st, Aop, N, Bop, NB, 0, tid);
-    for (int ch = 0; ch < NB / KC; ++ch) {
-      __syncthreads();
-      stage_store<false>(st, As, Bs, tid);
-      __syncthreads();
-      if (ch + 1 < NB / KC) stage_load<false>(st, Aop, N, Bop, NB, ch + 1, tid);
-      chunk_mfma<SKIP_LOWER>(As, Bs, acc, wave, lane, ch);
-    }
-    // acc[t][rr] = C[m = 16*wave + lk + 4rr][nn = 16t + lr]
+    tile_product_dma<SKIP_LOWER>(Aop, N, Bop, NB, lds, acc, wave, lane);
     if (I > k) {
       double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + k * NB + lr;
 #pragma unroll
