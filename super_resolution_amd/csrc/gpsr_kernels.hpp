@@ -209,7 +209,6 @@ __global__ void k_build(const double* __restrict__ X, const float* __restrict__ 
 // levels (W = T L^-T, A -= W W^T, T <- W L^-1) keeps the error at the level of an
 // unblocked sweep; forming A -= (T P) T^T with an explicit block inverse loses
 // sqrt(cond) digits per level (measured: DESIGN.md "Numerics of the inversion").
-#define PV_LD 113
 #define PV_DLD 17
 
 // In registers, C/D lane layout (lane: lr = lane&15, lk = lane>>4; a[c] = D[lk+4c][lr]):
@@ -253,155 +252,166 @@ __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, d
   *ld += log(prod);
 }
 
-__global__ void __launch_bounds__(MM_THREADS)
+// Block-packed LDS image of the pivot block: the 28 lower 16x16 blocks, each [16][17];
+// (i,j), i >= j, at block index i(i+1)/2 + j.  60.9 KB + 15.2 KB of per-wave transpose
+// scratch = 76 KB -> two workgroups per CU (the 16x16 register factorisations are a serial,
+// latency-bound chain: a second resident workgroup fills the bubbles).
+#define PV_BLK (16 * PV_DLD)
+#define PV_NBLK (NBT * (NBT + 1) / 2)
+#define SB(i, j) (S + (((i) * ((i) + 1)) / 2 + (j)) * PV_BLK)
+
+__global__ void __launch_bounds__(MM_THREADS, 4)
 k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double* __restrict__ Mbuf,
         double* __restrict__ logdet, int32_t* __restrict__ flags) {
   extern __shared__ double sm[];
-  double* S = sm;                          // [NB][PV_LD]
-  double* Dinv = sm + NB * PV_LD;          // [NBT][16][PV_DLD]  inv(L16_q), [row][col]
-  double* Tr = Dinv + NBT * 16 * PV_DLD;   // [NBT waves][16][PV_DLD] per-wave transpose scratch
+  double* S = sm;                           // [PV_NBLK][16][PV_DLD]
+  double* Tr = sm + PV_NBLK * PV_BLK;       // [NBT waves][16][PV_DLD] per-wave transpose scratch
   const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   double* Akk = A + (size_t)b * N * N + (size_t)(k * NB) * N + k * NB;
-  for (int e = tid; e < NB * NB; e += MM_THREADS) {
-    const int i = e / NB, j = e % NB;
-    S[i * PV_LD + j] = Akk[(size_t)i * N + j];
+  for (int e = tid; e < PV_NBLK * 256; e += MM_THREADS) {
+    const int blk = e >> 8, r = (e >> 4) & 15, c = e & 15;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+    const int bj = blk - bi * (bi + 1) / 2;
+    S[blk * PV_BLK + r * PV_DLD + c] = Akk[(size_t)(16 * bi + r) * N + 16 * bj + c];
   }
   __syncthreads();
   double ld = 0.0;
   int bad = 0;
-  double* tr = Tr + wave * 16 * PV_DLD;
-  // ---------------- phase 1: blocked Cholesky
+  double* tr = Tr + wave * PV_BLK;
+  // ---------------- phase 1: blocked Cholesky; afterwards SB(q,q) = inv(L16_q), SB(w,q) = L[w,q]
+  // The 16x16 factor+inverse is a serial register kernel: ONE wave (the owner of the diagonal
+  // block) runs it and publishes inv(L16_q) in place; the other workgroup resident on the CU
+  // fills the SIMDs meanwhile.
   for (int q = 0; q < NBT; ++q) {
-    double a[4], m[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) a[c] = S[(16 * q + lk + 4 * c) * PV_LD + 16 * q + lr];
-    chol16_inv(a, m, lane, &ld, &bad);
     if (wave == q) {
-      // only inv(L16) is needed later; S[q,q] itself must stay untouched here: slower
-      // waves may still be loading it for their own (redundant) factorisation
+      double a[4], m[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) Dinv[(q * 16 + lk + 4 * c) * PV_DLD + lr] = m[c];
-    } else if (wave > q) {
-      // L_wq = S[w,q] * inv(L16)^T : B operand element (k, col) = m16[col][k] -> transpose via scratch
+      for (int c = 0; c < 4; ++c) a[c] = SB(q, q)[(lk + 4 * c) * PV_DLD + lr];
+      chol16_inv(a, m, lane, &ld, &bad);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) tr[(lk + 4 * c) * PV_DLD + lr] = m[c];
-      __builtin_amdgcn_wave_barrier();
-      v4d cw = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const double av = S[(16 * wave + lr) * PV_LD + 16 * q + lk + 4 * ks];
-        const double bv = tr[lr * PV_DLD + lk + 4 * ks];
-        cw = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, cw, 0, 0, 0);
-      }
-      __builtin_amdgcn_wave_barrier();
-#pragma unroll
-      for (int c = 0; c < 4; ++c) S[(16 * wave + lk + 4 * c) * PV_LD + 16 * q + lr] = cw[c];
+      for (int c = 0; c < 4; ++c) SB(q, q)[(lk + 4 * c) * PV_DLD + lr] = m[c];
     }
     __syncthreads();
     if (wave > q) {
+      // L_wq = S[w,q] * inv(L16)^T : B operand element (k, col) = inv(L16)[col][k]
+      const double* Mqq = SB(q, q);
+      double* Swq = SB(wave, q);
+      v4d cw = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        cw = __builtin_amdgcn_mfma_f64_16x16x4f64(Swq[lr * PV_DLD + lk + 4 * ks], Mqq[lr * PV_DLD + lk + 4 * ks], cw,
+                                                  0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Swq[(lk + 4 * c) * PV_DLD + lr] = cw[c];
+    }
+    __syncthreads();   // panel column q written
+    if (wave > q) {
+      const double* Swq = SB(wave, q);
       double an[4];
 #pragma unroll
-      for (int ks = 0; ks < 4; ++ks) an[ks] = -S[(16 * wave + lr) * PV_LD + 16 * q + lk + 4 * ks];
+      for (int ks = 0; ks < 4; ++ks) an[ks] = -Swq[lr * PV_DLD + lk + 4 * ks];
       for (int j = q + 1; j <= wave; ++j) {
+        double* Swj = SB(wave, j);
+        const double* Sjq = SB(j, q);
         v4d acc;
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[c] = S[(16 * wave + lk + 4 * c) * PV_LD + 16 * j + lr];
+        for (int c = 0; c < 4; ++c) acc[c] = Swj[(lk + 4 * c) * PV_DLD + lr];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const double bv = S[(16 * j + lr) * PV_LD + 16 * q + lk + 4 * ks];
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(an[ks], bv, acc, 0, 0, 0);
-        }
+        for (int ks = 0; ks < 4; ++ks)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(an[ks], Sjq[lr * PV_DLD + lk + 4 * ks], acc, 0, 0, 0);
 #pragma unroll
-        for (int c = 0; c < 4; ++c) S[(16 * wave + lk + 4 * c) * PV_LD + 16 * j + lr] = acc[c];
+        for (int c = 0; c < 4; ++c) Swj[(lk + 4 * c) * PV_DLD + lr] = acc[c];
       }
     }
     __syncthreads();
   }
-  // ---------------- phase 2: M = L^-1, column block q = wave; U[q,w] = M[w,q]^T into the upper blocks
+  // every wave factored one diagonal block: combine log-determinant and flags
   {
-    const int q = wave;
-    v4d Mt[NBT];
-#pragma unroll
-    for (int t = 0; t < NBT; ++t) Mt[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-    for (int t = 0; t < NBT; ++t)
-      if (t == q) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) Mt[t][c] = Dinv[(q * 16 + lk + 4 * c) * PV_DLD + lr];
-      }
-#pragma unroll
-    for (int w = 1; w < NBT; ++w) {
-      if (w > q) {
-        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int t = 0; t < w; ++t) {
-          if (t >= q) {
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-              const double av = S[(16 * w + lr) * PV_LD + 16 * t + lk + 4 * ks];  // L[w,t]
-              acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Mt[t][ks], acc, 0, 0, 0);
-            }
-          }
-        }
-        v4d res = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-        for (int ks = 0; ks < 4; ++ks) {
-          const double av = Dinv[(w * 16 + lr) * PV_DLD + lk + 4 * ks];  // inv(L16_w)[lr][k]
-          res = __builtin_amdgcn_mfma_f64_16x16x4f64(av, -acc[ks], res, 0, 0, 0);
-        }
-        Mt[w] = res;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) S[(16 * q + lr) * PV_LD + 16 * w + lk + 4 * c] = res[c];  // U[q,w]
-      }
+    __shared__ double ldsum[NBT];
+    __shared__ int badsum[NBT];
+    if (lane == 0) { ldsum[wave] = ld; badsum[wave] = bad; }
+    __syncthreads();
+    if (tid == 0) {
+      ld = 0.0; bad = 0;
+      for (int w = 0; w < NBT; ++w) { ld += ldsum[w]; bad |= badsum[w]; }
     }
   }
-  __syncthreads();
-  // ---------------- phase 3: P = U U^T, wave a computes P[a, 0..a]; A_kk <- -P (both triangles)
+  // ---------------- phase 2: M = L^-1 in place, block columns from right to left:
+  //   M[w,q] = -(sum_{t=q+1..w} M[w,t] L[t,q]) inv(L16_q),   w > q
+  for (int q = NBT - 2; q >= 0; --q) {
+    v4d res = (v4d){0.0, 0.0, 0.0, 0.0};
+    if (wave > q) {
+      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int t = q + 1; t <= wave; ++t) {
+        const double* Mwt = SB(wave, t);   // t == wave: inv(L16_w)
+        const double* Ltq = SB(t, q);
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks)
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Mwt[lr * PV_DLD + lk + 4 * ks], Ltq[(lk + 4 * ks) * PV_DLD + lr],
+                                                     acc, 0, 0, 0);
+      }
+      // acc (C/D layout) as the A operand of acc * inv(L16_q): transpose through the scratch
+#pragma unroll
+      for (int c = 0; c < 4; ++c) tr[(lk + 4 * c) * PV_DLD + lr] = -acc[c];
+      __builtin_amdgcn_wave_barrier();
+      const double* Mqq = SB(q, q);
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks)
+        res = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[lr * PV_DLD + lk + 4 * ks], Mqq[(lk + 4 * ks) * PV_DLD + lr],
+                                                   res, 0, 0, 0);
+      __builtin_amdgcn_wave_barrier();
+    }
+    __syncthreads();   // all reads of L[.,q] done
+    if (wave > q) {
+      double* Swq = SB(wave, q);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) Swq[(lk + 4 * c) * PV_DLD + lr] = res[c];
+    }
+    __syncthreads();
+  }
+  // ---------------- phase 3: P = M^T M, wave a computes P[a, 0..a]; A_kk <- -P (both triangles)
   {
     const int a = wave;
+    for (int bb = 0; bb <= a; ++bb) {
+      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
+      for (int t = a; t < NBT; ++t) {
+        const double* Mta = SB(t, a);
+        const double* Mtb = SB(t, bb);
 #pragma unroll
-    for (int bb = 0; bb < NBT; ++bb) {
-      if (bb <= a) {
-        v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-        for (int t = a; t < NBT; ++t) {
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            const int kk = lk + 4 * ks;
-            // A operand: U[a,t][lr][kk] ; B operand: U[bb,t][col=lr][kk]
-            const double av = (t == a) ? Dinv[(a * 16 + kk) * PV_DLD + lr] : S[(16 * a + lr) * PV_LD + 16 * t + kk];
-            const double bv = (t == bb) ? Dinv[(bb * 16 + kk) * PV_DLD + lr] : S[(16 * bb + lr) * PV_LD + 16 * t + kk];
-            acc = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc, 0, 0, 0);
-          }
+        for (int ks = 0; ks < 4; ++ks) {
+          const int kk = lk + 4 * ks;
+          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Mta[kk * PV_DLD + lr], Mtb[kk * PV_DLD + lr], acc, 0, 0, 0);
         }
+      }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          Akk[(size_t)(16 * a + lk + 4 * c) * N + 16 * bb + lr] = -acc[c];
-          if (bb != a) Akk[(size_t)(16 * bb + lr) * N + 16 * a + lk + 4 * c] = -acc[c];
-        }
+      for (int c = 0; c < 4; ++c) {
+        Akk[(size_t)(16 * a + lk + 4 * c) * N + 16 * bb + lr] = -acc[c];
+        if (bb != a) Akk[(size_t)(16 * bb + lr) * N + 16 * a + lk + 4 * c] = -acc[c];
       }
     }
   }
-  // ---------------- phase 4: U (upper) and M = U^T (lower) to global, dense NBxNB row-major
+  // ---------------- phase 4: the non-zero 16x16 blocks of M (lower) and U = M^T (upper) to global.
+  // The zero blocks are never written: the panel / update kernels skip the products that would read them.
   double* Ub = Ubuf + (size_t)b * NB * NB;
   double* Mb = Mbuf + (size_t)b * NB * NB;
-  for (int e = tid; e < NB * NB; e += MM_THREADS) {
-    const int i = e / NB, j = e % NB;
-    const int bi = i >> 4, bj = j >> 4;
-    double u = 0.0, mv = 0.0;
-    if (bi < bj) u = S[i * PV_LD + j];
-    else if (bi == bj) u = Dinv[(bi * 16 + (j & 15)) * PV_DLD + (i & 15)];   // U[i][j] = M16[j][i]
-    if (bj < bi) mv = S[j * PV_LD + i];                                       // M[i][j] = U[j][i]
-    else if (bi == bj) mv = Dinv[(bi * 16 + (i & 15)) * PV_DLD + (j & 15)];
-    Ub[e] = u;
-    Mb[e] = mv;
+  for (int e = tid; e < PV_NBLK * 256; e += MM_THREADS) {
+    const int blk = e >> 8, r = (e >> 4) & 15, c = e & 15;
+    int bi = 0;
+    while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+    const int bj = blk - bi * (bi + 1) / 2;
+    Mb[(16 * bi + r) * NB + 16 * bj + c] = S[blk * PV_BLK + r * PV_DLD + c];   // M[i][j]
+    Ub[(16 * bj + r) * NB + 16 * bi + c] = S[blk * PV_BLK + c * PV_DLD + r];   // U[j][i] = M[i][j]
   }
   if (tid == 0) {
     logdet[b] += ld;
     if (bad) flags[b] = 1;
   }
 }
-#define PIVOT_LDS_BYTES ((NB * PV_LD + 2 * NBT * 16 * PV_DLD) * sizeof(double))
+#define PIVOT_LDS_BYTES ((PV_NBLK * PV_BLK + NBT * PV_BLK) * sizeof(double))
+
 
 // ------------------------------------------------- shared MFMA tile product
 // acc[t] (16 rows of this wave x 16 cols of tile t) += sum_kk Aop[kk][16*wave + .] * Bop[kk][16*t + .]
