@@ -118,7 +118,11 @@ static int launch_build(const double* X, int B, int n, int N, int d, int kid, co
                         double* logdet, hipStream_t st) {
   const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2, total = ntri * B;
   const size_t lds = build_lds(d);
-#define BUILD(K) hipLaunchKernelGGL((k_build<K>), dim3(total), dim3(256), lds, st, X, raw, A, n, N, d, ntri, total, logdet)
+#define BUILD(K)                                                                                              \
+  do {                                                                                                        \
+    if (d == 8) hipLaunchKernelGGL((k_build8<K>), dim3(total), dim3(MM_THREADS), 0, st, X, raw, A, n, N, ntri, total, logdet); \
+    else hipLaunchKernelGGL((k_build<K>), dim3(total), dim3(256), lds, st, X, raw, A, n, N, d, ntri, total, logdet);           \
+  } while (0)
   ProfRec* pr = prof_start(T_BUILD, st);
   switch (kid) {
     case K_RBF: BUILD(K_RBF); break;
@@ -142,14 +146,13 @@ extern "C" int gpsr_covariance(const double* X, int B, int n, int d, int kernel_
 }
 
 // ---------------------------------------------------------------- inversion
-struct InvWs { double *Wn, *Wo, *U, *M; };
+struct InvWs { double *Wo, *U, *M; };
 
 static size_t inv_ws_bytes(int B, int N) {
-  return 2 * align256((size_t)B * NB * N * 8) + 2 * align256((size_t)B * NB * NB * 8);
+  return align256((size_t)B * NB * N * 8) + 2 * align256((size_t)B * NB * NB * 8);
 }
 static InvWs inv_ws_carve(char* base, int B, int N) {
   InvWs w;
-  w.Wn = (double*)base; base += align256((size_t)B * NB * N * 8);
   w.Wo = (double*)base; base += align256((size_t)B * NB * N * 8);
   w.U = (double*)base; base += align256((size_t)B * NB * NB * 8);
   w.M = (double*)base;
@@ -174,12 +177,12 @@ static int launch_sweeps(double* A, int B, int N, const InvWs& w, double* logdet
     if (nblk > 1) {
       const int tp = (nblk - 1) * B;
       pr = prof_start(T_PANEL, st);
-      hipLaunchKernelGGL(k_panel, dim3(tp), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.U, w.Wn, w.Wo, tp);
+      hipLaunchKernelGGL(k_panel, dim3(tp), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.U, w.Wo, tp);
       prof_stop(pr, st);
       CHECK_LAUNCH("k_panel");
       const int ntri1 = (nblk - 1) * nblk / 2, tu = (ntri1 + nblk - 1) * B;
       pr = prof_start(T_UPDATE, st);
-      hipLaunchKernelGGL(k_update, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wn, w.Wo, w.M, ntri1, tu);
+      hipLaunchKernelGGL(k_update, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M, ntri1, tu);
       prof_stop(pr, st);
       CHECK_LAUNCH("k_update");
     }
@@ -239,7 +242,11 @@ static int launch_grad2(const FitWs& w, const double* X, const float* raw, const
                         int N, int d, int kid, hipStream_t st) {
   const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2, total = ntri * B;
   const size_t lds = build_lds(d) + 2 * NB * sizeof(double);
-#define G2(K) hipLaunchKernelGGL((k_grad2<K>), dim3(total), dim3(256), lds, st, w.A, X, raw, alpha, n, N, d, ntri, total, w.stats2)
+#define G2(K)                                                                                                 \
+  do {                                                                                                        \
+    if (d == 8) hipLaunchKernelGGL((k_grad2_8<K>), dim3(total), dim3(MM_THREADS), 0, st, w.A, X, raw, alpha, n, N, ntri, total, w.stats2); \
+    else hipLaunchKernelGGL((k_grad2<K>), dim3(total), dim3(256), lds, st, w.A, X, raw, alpha, n, N, d, ntri, total, w.stats2);            \
+  } while (0)
   ProfRec* pr = prof_start(T_GRAD2, st);
   switch (kid) {
     case K_RBF: G2(K_RBF); break;
@@ -322,7 +329,6 @@ extern "C" int gpsr_loss_grad(const double* X, const double* y, int B, int n, in
   FitWs w = fit_ws_carve((char*)workspace, B, N);
   hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
   if (e != hipSuccess) return hip_fail(e, "memset flags");
-  // alpha scratch: reuse the (unused here) Wn panel tail?  No: keep it simple, alpha lives in stats-free space of Wo.
   double* alpha = w.inv.Wo;  // [B][N] fits in [B][NB][N]; Wo is dead after the sweeps
   rc = eval_once(w, X, y, raw, alpha, flags, B, n, N, d, kernel_id, true, st);
   if (rc) return rc;

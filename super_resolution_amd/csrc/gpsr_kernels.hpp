@@ -3,8 +3,7 @@
 // Layout conventions
 //   A      [B][N][N] f64 row-major, N = nblk*NB.  Only block (I,J) with I>=J is
 //          maintained ("lower block-triangle"); diagonal blocks are kept full.
-//   Wn, Wo [B][NB][N]  k-major panels of the current pivot step, W = A_.k L^-T:
-//          Wo[kk][r] = W[r][kk],  Wn = -Wo
+//   Wo     [B][NB][N]  k-major panel of the current pivot step, W = A_.k L^-T: Wo[kk][r] = W[r][kk]
 //   U, M   [B][NB][NB] U = L^-T (upper), M = L^-1 (lower) of the current pivot block A_kk = L L^T
 //   raw    [B][4] f32  raw hyper-parameters (noise, const, outputscale, lengthscale)
 //
@@ -28,7 +27,7 @@ typedef double v4d __attribute__((ext_vector_type(4)));
 
 enum { K_RBF = 0, K_M12 = 1, K_M32 = 2, K_M52 = 3, K_LIN = 4 };
 
-struct Hyp { double noise, mean, os, ls; };
+struct Hyp { double noise, mean, os, ls, il, il2; };   // il = 1/ls, il2 = 1/ls^2 (once per thread: the pair loops multiply)
 
 __device__ __forceinline__ float softplus_f(float x) { return x > 20.f ? x : log1pf(expf(x)); }
 __device__ __forceinline__ float sigmoid_f(float x) { return 1.f / (1.f + expf(-x)); }
@@ -39,15 +38,17 @@ __device__ __forceinline__ Hyp load_hyp(const float* __restrict__ raw) {
   h.mean = (double)raw[1];
   h.os = (double)softplus_f(raw[2]);
   h.ls = (double)softplus_f(raw[3]);
+  h.il = 1.0 / h.ls;
+  h.il2 = 1.0 / (h.ls * h.ls);
   return h;
 }
 
 // base kernel value from the pair statistic (squared distance, or dot product for linear)
 template <int KID>
-__device__ __forceinline__ double kern_val(double st, double ls) {
-  if (KID == K_LIN) return ls * st;
-  if (KID == K_RBF) return exp(-0.5 * st / (ls * ls));
-  double r = sqrt(fmax(st / (ls * ls), 1e-30));
+__device__ __forceinline__ double kern_val(double st, const Hyp& h) {
+  if (KID == K_LIN) return h.ls * st;
+  if (KID == K_RBF) return exp(-0.5 * st * h.il2);
+  double r = sqrt(fmax(st * h.il2, 1e-30));
   if (KID == K_M12) return exp(-r);
   if (KID == K_M32) { double s = 1.7320508075688772 * r; return (s + 1.0) * exp(-s); }
   double s = 2.23606797749979 * r;
@@ -56,18 +57,18 @@ __device__ __forceinline__ double kern_val(double st, double ls) {
 
 // value and d/d(lengthscale) (d/d(variance) for linear)
 template <int KID>
-__device__ __forceinline__ void kern_val_dl(double st, double ls, double& k, double& dk) {
-  if (KID == K_LIN) { k = ls * st; dk = st; return; }
-  if (KID == K_RBF) { k = exp(-0.5 * st / (ls * ls)); dk = k * st / (ls * ls * ls); return; }
-  double r = sqrt(fmax(st / (ls * ls), 1e-30));
-  if (KID == K_M12) { k = exp(-r); dk = k * r / ls; return; }
+__device__ __forceinline__ void kern_val_dl(double st, const Hyp& h, double& k, double& dk) {
+  if (KID == K_LIN) { k = h.ls * st; dk = st; return; }
+  if (KID == K_RBF) { k = exp(-0.5 * st * h.il2); dk = k * st * h.il2 * h.il; return; }
+  double r = sqrt(fmax(st * h.il2, 1e-30));
+  if (KID == K_M12) { k = exp(-r); dk = k * r * h.il; return; }
   if (KID == K_M32) {
     double s = 1.7320508075688772 * r, e = exp(-s);
-    k = (s + 1.0) * e; dk = 3.0 * r * r * e / ls; return;
+    k = (s + 1.0) * e; dk = 3.0 * r * r * e * h.il; return;
   }
   double s = 2.23606797749979 * r, e = exp(-s);
   k = (s + 1.0 + (5.0 / 3.0) * r * r) * e;
-  dk = (5.0 / 3.0) * r * r * (1.0 + s) * e / ls;
+  dk = (5.0 / 3.0) * r * r * (1.0 + s) * e * h.il;
 }
 
 template <int KID>
@@ -187,12 +188,53 @@ __global__ void k_build(const double* __restrict__ X, const float* __restrict__ 
     double val;
     if (gi < n && gj < n) {
       double st = pair_stat<KID>(xi + i * ldx, xj + j * ldx, d);
-      val = h.os * kern_val<KID>(st, h.ls);
+      val = h.os * kern_val<KID>(st, h);
       if (gi == gj) val += h.noise;
     } else {
       val = (gi == gj) ? 1.0 : 0.0;
     }
     Ab[(size_t)gi * N + gj] = val;
+  }
+}
+
+// d == 8 fast path (the SRGPR feature vector): 448 threads; thread (g, j) = (tid / NB, tid % NB)
+// keeps column point x_j in registers and walks rows i = g, g+4, ...; the row point x_i
+// is an LDS broadcast (one address per wave, up to the g boundary).  Same per-element
+// arithmetic as k_build, element order only.
+template <int KID>
+__global__ void __launch_bounds__(MM_THREADS)
+k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __restrict__ A, int n, int N,
+         int ntri, int total, double* __restrict__ logdet) {
+  __shared__ __attribute__((aligned(16))) double xi[NB * 8];
+  const int v = xcd_remap(blockIdx.x, total);
+  const int b = v / ntri, t = v % ntri;
+  int I, J; tri_decode(t, I, J);
+  const int tid = threadIdx.x, g = tid / NB, j = tid - g * NB;
+  const double* Xb = X + (size_t)b * n * 8;
+  const int gj = J * NB + j;
+  double xj[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) xj[f] = gj < n ? Xb[(size_t)gj * 8 + f] : 0.0;
+  for (int e = tid; e < NB * 8; e += MM_THREADS) {
+    const int gi = I * NB + (e >> 3);
+    xi[e] = gi < n ? Xb[(size_t)I * NB * 8 + e] : 0.0;
+  }
+  const Hyp h = load_hyp(raw + 4 * b);
+  if (t == 0 && tid == 0 && logdet) logdet[b] = 0.0;
+  __syncthreads();
+  double* Ab = A + (size_t)b * N * N + (size_t)(I * NB) * N + gj;
+#pragma unroll 2
+  for (int i = g; i < NB; i += 4) {
+    const int gi = I * NB + i;
+    double val;
+    if (gi < n && gj < n) {
+      const double st = pair_stat<KID>(xi + i * 8, xj, 8);
+      val = h.os * kern_val<KID>(st, h);
+      if (gi == gj) val += h.noise;
+    } else {
+      val = (gi == gj) ? 1.0 : 0.0;
+    }
+    Ab[(size_t)i * N] = val;
   }
 }
 
@@ -266,7 +308,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   extern __shared__ double sm[];
   double* S = sm;                           // [PV_NBLK][16][PV_DLD]
   double* Tr = sm + PV_NBLK * PV_BLK;       // [NBT waves][16][PV_DLD] per-wave transpose scratch
-  const int b = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int b = blockIdx.x, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   double* Akk = A + (size_t)b * N * N + (size_t)(k * NB) * N + k * NB;
   for (int e = tid; e < PV_NBLK * 256; e += MM_THREADS) {
@@ -421,7 +463,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
 // SKIP: Bop is block-triangular at 16x16 granularity, skip the zero products:
 //   SKIP_UPPER  Bop[kk][c] == 0 unless tile(c) >= chunk(kk)
 //   SKIP_LOWER  Bop[kk][c] == 0 unless tile(c) <= chunk(kk)
-enum { SKIP_NONE = 0, SKIP_UPPER = 1, SKIP_LOWER = 2 };
+enum { SKIP_NONE = 0, SKIP_UPPER = 1, SKIP_LOWER = 2, SKIP_DIAG = 3 };   // SKIP_DIAG: symmetric result, wave w computes blocks t <= w only
 struct Stage { double a[4]; double b[4]; };
 
 template <bool TRANS_A>
@@ -488,11 +530,12 @@ __device__ __forceinline__ void chunk_mfma(const double* __restrict__ As, const 
 // (per-wave 16x17 LDS scratch; the staging buffers must be free)
 __device__ __forceinline__ void store_strip_transposed(const v4d acc[NBT], double* __restrict__ dst, size_t ld,
                                                        double* __restrict__ scratch, int wave, int lane,
-                                                       double sign, double* __restrict__ dst2) {
+                                                       double sign, double* __restrict__ dst2, int tmax = NBT) {
   const int lr = lane & 15, lk = lane >> 4;
   double* tr = scratch + wave * (16 * 17);
 #pragma unroll
   for (int t = 0; t < NBT; ++t) {
+    if (t >= tmax) break;
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) tr[(lk + 4 * rr) * 17 + lr] = acc[t][rr];  // [row][col]
     __builtin_amdgcn_wave_barrier();
@@ -512,13 +555,13 @@ __device__ __forceinline__ void store_strip_transposed(const v4d acc[NBT], doubl
 // grid.x = (nblk-1) * B.  For row block i != k, T = A_ik (block (i,k) row-major when i > k,
 // block (k,i) = T^T, i.e. k-major, when i < k):
 //   W = T L^-T = T U :  acc[r][k'] = sum_kk T[r][kk] U[kk][k']   (U upper: SKIP_UPPER)
-//   Wo[k'][i0+r] = W ,  Wn[k'][i0+r] = -W     (k-major panels for the update)
+//   Wo[k'][i0+r] = W     (k-major panel for the update)
 __global__ void __launch_bounds__(MM_THREADS, 4)
 k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Ubuf,
-        double* __restrict__ Wn, double* __restrict__ Wo, int total) {
+        double* __restrict__ Wo, int total) {
   __shared__ double lds[2 * KC * LDS_LD];
   double* As = lds; double* Bs = lds + KC * LDS_LD;
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int v = xcd_remap(blockIdx.x, total);
   const int b = v / (nblk - 1);
   int i = v % (nblk - 1); if (i >= k) ++i;
@@ -542,14 +585,13 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
     chunk_mfma<SKIP_UPPER>(As, Bs, acc, wave, lane, ch);
   }
   __syncthreads();
-  // acc[t][rr] = W[r = 16*wave + lk + 4rr][k' = 16t + lr]  ->  Wo[k'][i0 + r], Wn = -W
-  store_strip_transposed(acc, Wo + (size_t)b * NB * N + i0, (size_t)N, lds, wave, lane, 1.0,
-                         Wn + (size_t)b * NB * N + i0);
+  // acc[t][rr] = W[r = 16*wave + lk + 4rr][k' = 16t + lr]  ->  Wo[k'][i0 + r]
+  store_strip_transposed(acc, Wo + (size_t)b * NB * N + i0, (size_t)N, lds, wave, lane, 1.0, nullptr);
 }
 
 // ----------------------------------------------------------------- update
 // grid.x = (ntri(nblk-1) + nblk-1) * B.  Two kinds of 112x112 tile products:
-//   trailing tile (I,J), I >= J, I,J != k:   A_IJ -= W_I W_J^T      (Aop = Wn_I, Bop = Wo_J)
+//   trailing tile (I,J), I >= J, I,J != k:   A_IJ -= W_I W_J^T      (Aop = -Wo_I, Bop = Wo_J)
 //   pivot-column tile I != k:                A_Ik  = W_I L^-1 = W_I M (Aop = Wo_I, Bop = M lower: SKIP_LOWER)
 //     stored row-major into block (I,k) when I > k, transposed into block (k,I) when I < k.
 // The 16-deep operand chunks go global -> LDS directly (global_load_lds_dwordx4: no VGPR
@@ -577,24 +619,26 @@ __device__ __forceinline__ void dma_chunk(const double* __restrict__ Aop, int ld
   }
 }
 
-template <int SKIP>
+template <int SKIP, bool NEG_A>
 __device__ __forceinline__ void chunk_mfma_dma(const double* __restrict__ As, const double* __restrict__ Bs,
                                                v4d acc[NBT], int wave, int lane, int ch) {
   const int lr = lane & 15, lk = lane >> 4;
 #pragma unroll
   for (int ks = 0; ks < KC / 4; ++ks) {
     const int row = (ks * 4 + lk) * NB;
-    const double av = As[row + 16 * wave + lr];
+    const double a0 = As[row + 16 * wave + lr];
+    const double av = NEG_A ? -a0 : a0;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) {
       if (SKIP == SKIP_LOWER && t > ch) continue;
+      if (SKIP == SKIP_DIAG && t > wave) continue;
       const double bv = Bs[row + 16 * t + lr];
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
     }
   }
 }
 
-template <int SKIP>
+template <int SKIP, bool NEG_A>
 __device__ __forceinline__ void tile_product_dma(const double* __restrict__ Aop, int lda,
                                                  const double* __restrict__ Bop, int ldb, double* __restrict__ lds,
                                                  v4d acc[NBT], int wave, int lane) {
@@ -606,15 +650,47 @@ __device__ __forceinline__ void tile_product_dma(const double* __restrict__ Aop,
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk ch have landed
     __syncthreads();                                   // everyone's have; everyone is done reading `nxt`
     if (ch + 1 < NB / KC) dma_chunk(Aop, lda, Bop, ldb, ch + 1, nxt, nxt + DMA_CHUNK, wave, lane);
-    chunk_mfma_dma<SKIP>(cur, cur + DMA_CHUNK, acc, wave, lane, ch);
+    chunk_mfma_dma<SKIP, NEG_A>(cur, cur + DMA_CHUNK, acc, wave, lane, ch);
+  }
+}
+
+// Same product for a trailing tile C -= ..., with the read of C taken off the critical
+// path: chunk 0's DMA is issued first, then the 28 loads of the wave's C strip; chunk 0
+// runs on zeroed accumulators as soon as the DMA (older in vmcnt order) has landed, and
+// C is added when the loads have (before chunk 1).
+__device__ __forceinline__ void tile_product_dma_latec(const double* __restrict__ Aop, int lda,
+                                                       const double* __restrict__ Bop, int ldb,
+                                                       double* __restrict__ lds, v4d acc[NBT],
+                                                       const double* __restrict__ Ct, size_t ldc, int wave, int lane) {
+  dma_chunk(Aop, lda, Bop, ldb, 0, lds, lds + DMA_CHUNK, wave, lane);
+  v4d c0[NBT];
+#pragma unroll
+  for (int t = 0; t < NBT; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) c0[t][rr] = Ct[(size_t)(4 * rr) * ldc + 16 * t];
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  asm volatile("s_waitcnt vmcnt(28)" ::: "memory");    // chunk 0's 4 DMA pieces (older than the 28 C loads) have landed
+  __builtin_amdgcn_s_barrier();                        // bare barrier: __syncthreads' fence would drain vmcnt to 0
+  dma_chunk(Aop, lda, Bop, ldb, 1, lds + 2 * DMA_CHUNK, lds + 3 * DMA_CHUNK, wave, lane);
+  chunk_mfma_dma<SKIP_NONE, true>(lds, lds + DMA_CHUNK, acc, wave, lane, 0);
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) acc[t] += c0[t];   // the compiler folds these in as each acc[t] finishes chunk 0
+  for (int ch = 1; ch < NB / KC; ++ch) {
+    double* cur = lds + (ch & 1) * 2 * DMA_CHUNK;
+    double* nxt = lds + ((ch + 1) & 1) * 2 * DMA_CHUNK;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ch + 1 < NB / KC) dma_chunk(Aop, lda, Bop, ldb, ch + 1, nxt, nxt + DMA_CHUNK, wave, lane);
+    chunk_mfma_dma<SKIP_NONE, true>(cur, cur + DMA_CHUNK, acc, wave, lane, ch);
   }
 }
 
 __global__ void __launch_bounds__(MM_THREADS, 4)
-k_update(double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Wn,
+k_update(double* __restrict__ A, int N, int nblk, int k,
              const double* __restrict__ Wo, const double* __restrict__ Mbuf, int ntri1, int total) {
   __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
-  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int v = xcd_remap(blockIdx.x, total);
   const int per = ntri1 + nblk - 1;
   const int b = v / per, t0 = v % per;
@@ -625,25 +701,38 @@ k_update(double* __restrict__ A, int N, int nblk, int k, const double* __restric
     int I, J; tri_decode(t0, I, J);
     if (I >= k) ++I;
     if (J >= k) ++J;
-    const double* Aop = Wn + (size_t)b * NB * N + I * NB;
+    const double* Aop = Wo + (size_t)b * NB * N + I * NB;   // used negated
     const double* Bop = Wo + (size_t)b * NB * N + J * NB;
     double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + J * NB + lr;
+    if (I == J) {
+      // symmetric diagonal tile: wave w computes the 16x16 blocks t <= w and mirrors t < w
 #pragma unroll
-    for (int t = 0; t < NBT; ++t)
+      for (int t = 0; t < NBT; ++t)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) acc[t][rr] = Ct[(size_t)(4 * rr) * N + 16 * t];
-    tile_product_dma<SKIP_NONE>(Aop, N, Bop, N, lds, acc, wave, lane);
+        for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * N + 16 * t] : 0.0;
+      tile_product_dma<SKIP_DIAG, true>(Aop, N, Bop, N, lds, acc, wave, lane);
 #pragma unroll
-    for (int t = 0; t < NBT; ++t)
+      for (int t = 0; t < NBT; ++t) {
+        if (t > wave) break;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+      }
+      __syncthreads();   // chunk buffers are free: per-wave transposition scratch
+      store_strip_transposed(acc, Ab + (size_t)(I * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr, wave);
+    } else {
+      tile_product_dma_latec(Aop, N, Bop, N, lds, acc, Ct, (size_t)N, wave, lane);
+#pragma unroll
+      for (int t = 0; t < NBT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+    }
   } else {
     int I = t0 - ntri1; if (I >= k) ++I;
     const double* Aop = Wo + (size_t)b * NB * N + I * NB;
     const double* Bop = Mbuf + (size_t)b * NB * NB;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_product_dma<SKIP_LOWER>(Aop, N, Bop, NB, lds, acc, wave, lane);
+    tile_product_dma<SKIP_LOWER, false>(Aop, N, Bop, NB, lds, acc, wave, lane);
     if (I > k) {
       double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + k * NB + lr;
 #pragma unroll
@@ -666,7 +755,7 @@ k_grad1(const double* __restrict__ A, int N, int n, int nblk, const double* __re
         const float* __restrict__ raw, double* __restrict__ alpha, double* __restrict__ stats1) {
   extern __shared__ double sm[];  // r[N] | part[4][NB] | rowacc[NB] | red[8*4]
   double* r = sm; double* part = sm + N; double* rowacc = part + 4 * NB; double* red = rowacc + NB;
-  const int I = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int I = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const double mean = (double)raw[4 * b + 1];
   const double* yb = y + (size_t)b * n;
   for (int i = tid; i < N; i += MM_THREADS) r[i] = i < n ? yb[i] - mean : 0.0;
@@ -752,7 +841,7 @@ __global__ void k_grad2(const double* __restrict__ A, const double* __restrict__
       double w = -Ab[(size_t)gi * N + gj] - ai[i] * aj[j];
       double st = pair_stat<KID>(xi + i * ldx, xj + j * ldx, d);
       double kv, dk;
-      kern_val_dl<KID>(st, h.ls, kv, dk);
+      kern_val_dl<KID>(st, h, kv, dk);
       s0 = fma(w, kv, s0);
       s1 = fma(w, dk, s1);
     }
@@ -766,6 +855,60 @@ __global__ void k_grad2(const double* __restrict__ A, const double* __restrict__
     double s = (red[threadIdx.x][0] + red[threadIdx.x][1]) + (red[threadIdx.x][2] + red[threadIdx.x][3]);
     if (I != J) s *= 2.0;
     stats2[((size_t)b * ntri + t) * 2 + threadIdx.x] = s;
+  }
+}
+
+// d == 8 fast path, same thread layout as k_build8 (x_j, alpha_j in registers; x_i, alpha_i LDS broadcasts).
+template <int KID>
+__global__ void __launch_bounds__(MM_THREADS)
+k_grad2_8(const double* __restrict__ A, const double* __restrict__ X, const float* __restrict__ raw,
+          const double* __restrict__ alpha, int n, int N, int ntri, int total, double* __restrict__ stats2) {
+  __shared__ __attribute__((aligned(16))) double xi[NB * 8];
+  __shared__ double ai[NB];
+  __shared__ double red[2][NBT];
+  const int v = xcd_remap(blockIdx.x, total);
+  const int b = v / ntri, t = v % ntri;
+  int I, J; tri_decode(t, I, J);
+  const int tid = threadIdx.x, g = tid / NB, j = tid - g * NB;
+  const double* Xb = X + (size_t)b * n * 8;
+  const int gj = J * NB + j;
+  double xj[8];
+#pragma unroll
+  for (int f = 0; f < 8; ++f) xj[f] = gj < n ? Xb[(size_t)gj * 8 + f] : 0.0;
+  const double aj = alpha[(size_t)b * N + gj];
+  for (int e = tid; e < NB * 8; e += MM_THREADS) {
+    const int gi = I * NB + (e >> 3);
+    xi[e] = gi < n ? Xb[(size_t)I * NB * 8 + e] : 0.0;
+  }
+  if (tid < NB) ai[tid] = alpha[(size_t)b * N + I * NB + tid];
+  const Hyp h = load_hyp(raw + 4 * b);
+  __syncthreads();
+  const double* Ab = A + (size_t)b * N * N + (size_t)(I * NB) * N + gj;
+  double s0 = 0.0, s1 = 0.0;
+  if (gj < n) {
+#pragma unroll 2
+    for (int i = g; i < NB; i += 4) {
+      if (I * NB + i < n) {
+        const double w = -Ab[(size_t)i * N] - ai[i] * aj;
+        const double st = pair_stat<KID>(xi + i * 8, xj, 8);
+        double kv, dk;
+        kern_val_dl<KID>(st, h, kv, dk);
+        s0 = fma(w, kv, s0);
+        s1 = fma(w, dk, s1);
+      }
+    }
+  }
+  const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); }
+  if (lane == 0) { red[0][wave] = s0; red[1][wave] = s1; }
+  __syncthreads();
+  if (tid < 2) {
+    double s = 0.0;
+#pragma unroll
+    for (int w = 0; w < NBT; ++w) s += red[tid][w];
+    if (I != J) s *= 2.0;
+    stats2[((size_t)b * ntri + t) * 2 + tid] = s;
   }
 }
 
@@ -849,7 +992,7 @@ k_predict(const double* __restrict__ X, const double* __restrict__ Xs, const dou
         if (KID == K_LIN) st = fma(q[u][f], xr[f], st);
         else { double dlt = q[u][f] - xr[f]; st = fma(dlt, dlt, st); }
       }
-      acc[u] = fma(kern_val<KID>(st, h.ls), a, acc[u]);
+      acc[u] = fma(kern_val<KID>(st, h), a, acc[u]);
     }
   }
 #pragma unroll
