@@ -149,6 +149,29 @@ int gpsr_combine(const double* pred, const double* test_in, int H, int W, int s,
                  double* out, void* stream);
 
 /*
+ * Fused K1..K6: GPRSR.predict_pixels (gprsr.py:126-210) for one image in one call --
+ * gather -> initial hyper-parameters -> `iters` Adam steps -> predictive mean ->
+ * ordered recombination (+ clip to [0,1], gprsr.py:208).  Every patch is fitted from
+ * the fresh initial values (warm_start "independent"; the serial chain of SURVEY.md F5
+ * is composed from the separate entry points with `carry`).
+ *   train_in, train_tgt : [H][W] f64     test_in : [H*s][W*s] f64
+ *   rows[nr], cols[nc]  : LR patch-corner grid (PatchHandler.patch_locations is its
+ *                         row-major product, duplicates kept), B = nr*nc patches
+ *   tidx[nt]            : per-axis training indices, n = nt*nt
+ *   chunk               : patches fitted per pass (1..B; 0 = all at once) -- bounds the workspace
+ *   out : [H*s][W*s] f64        raw_out : [B][4] f32 final raw hyper-parameters, or NULL
+ *   flags : [B] int32 (non-zero: a pivot was <= 0 at some iteration)
+ * Workspace size: gpsr_predict_pixels_workspace_bytes (same s, p, nt, B, chunk).
+ */
+size_t gpsr_predict_pixels_workspace_bytes(int s, int p, int nt, int B, int chunk);
+int gpsr_predict_pixels(const double* train_in, const double* train_tgt, const double* test_in,
+                        int H, int W, int s, int p, const int32_t* rows, int nr,
+                        const int32_t* cols, int nc, const int32_t* tidx, int nt,
+                        int kernel_id, float init_raw_os, float init_raw_ls, int iters, float lr,
+                        int mode, int chunk, double* out, float* raw_out, int32_t* flags,
+                        void* workspace, size_t workspace_bytes, void* stream);
+
+/*
  * K7 AGPR: the linear-kernel posterior mean is affine in the 7x7 window:
  * w[49] = outputscale * variance * X^T alpha.  gpsr_agpr_weights builds w from
  * a fitted model (agpr.py:58,176), gpsr_agpr_filter applies

@@ -35,6 +35,10 @@ SIGNATURES = {
     "gpsr_predict": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p]),
     "gpsr_combine": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_void_p, c_int,
                              c_int, c_int, c_void_p, c_void_p]),
+    "gpsr_predict_pixels_workspace_bytes": (c_size_t, [c_int] * 5),
+    "gpsr_predict_pixels": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_int, c_void_p, c_int]
+                            + [c_int, c_float, c_float, c_int, c_float, c_int, c_int]
+                            + [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gpsr_agpr_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "gpsr_agpr_filter": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gpsr_selftest_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),

@@ -385,6 +385,67 @@ extern "C" int gpsr_combine(const double* pred, const double* test_in, int H, in
   return 0;
 }
 
+// ---------------------------------------------------------------- fused predict_pixels
+struct PixWs { int32_t* locs; float* raw; double *pred, *X, *y, *Xs, *alpha; char* fit; };
+
+static size_t pix_ws_carve(char* base, int B, int Bc, int n, int m, PixWs* w) {
+  const int N = gpsr_padded_n(n);
+  size_t off = 0;
+#define CARVE(field, type, bytes) do { if (w) w->field = (type)(base + off); off += align256(bytes); } while (0)
+  CARVE(locs, int32_t*, (size_t)B * 2 * 4);
+  CARVE(raw, float*, (size_t)B * 4 * 4);
+  CARVE(pred, double*, (size_t)B * m * 8);
+  CARVE(X, double*, (size_t)Bc * n * 8 * 8);
+  CARVE(y, double*, (size_t)Bc * n * 8);
+  CARVE(Xs, double*, (size_t)Bc * m * 8 * 8);
+  CARVE(alpha, double*, (size_t)Bc * N * 8);
+#undef CARVE
+  if (w) w->fit = base + off;
+  return off + fit_ws_bytes(Bc, N);
+}
+
+extern "C" size_t gpsr_predict_pixels_workspace_bytes(int s, int p, int nt, int B, int chunk) {
+  if (s < 1 || p < 3 || nt < 1 || B < 1) return 0;
+  const int Bc = (chunk <= 0 || chunk > B) ? B : chunk;
+  return pix_ws_carve(nullptr, B, Bc, nt * nt, (p * s - 2) * (p * s - 2), nullptr);
+}
+
+extern "C" int gpsr_predict_pixels(const double* train_in, const double* train_tgt, const double* test_in,
+                                   int H, int W, int s, int p, const int32_t* rows, int nr,
+                                   const int32_t* cols, int nc, const int32_t* tidx, int nt,
+                                   int kernel_id, float init_raw_os, float init_raw_ls, int iters, float lr,
+                                   int mode, int chunk, double* out, float* raw_out, int32_t* flags,
+                                   void* workspace, size_t workspace_bytes, void* stream) {
+  if (!train_in || !train_tgt || !test_in || !rows || !cols || !tidx || !out || !flags || !workspace)
+    return arg_fail("null pointer");
+  if (nr < 1 || nc < 1 || p < 3 || s < 1 || p > H || p > W || nt < 1 || nt > p - 2) return arg_fail("patch geometry");
+  if (kernel_id < 0 || kernel_id > 4 || iters < 0 || (mode != 0 && mode != 1)) return arg_fail("kernel_id / iters / mode");
+  const int B = nr * nc, Bc = (chunk <= 0 || chunk > B) ? B : chunk;
+  const int n = nt * nt, m = (p * s - 2) * (p * s - 2), N = gpsr_padded_n(n);
+  if (n < 2 || N > 16 * NB) return arg_fail("n out of range (2..1792)");
+  if (workspace_bytes < gpsr_predict_pixels_workspace_bytes(s, p, nt, B, chunk)) return arg_fail("workspace too small");
+  PixWs w;
+  pix_ws_carve((char*)workspace, B, Bc, n, m, &w);
+  float* raw = raw_out ? raw_out : w.raw;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_make_locs, dim3((B + 255) / 256), dim3(256), 0, st, rows, cols, nr, nc, w.locs);
+  CHECK_LAUNCH("k_make_locs");
+  const size_t fit_bytes = fit_ws_bytes(Bc, N);
+  for (int b0 = 0; b0 < B; b0 += Bc) {
+    const int bn = (B - b0 < Bc) ? B - b0 : Bc;
+    int rc = gpsr_gather(train_in, train_tgt, test_in, H, W, s, p, w.locs + 2 * b0, bn, tidx, nt, w.X, w.y, w.Xs, stream);
+    if (rc) return rc;
+    rc = gpsr_init_hypers(w.y, bn, n, kernel_id, init_raw_os, init_raw_ls, nullptr, raw + 4 * b0, stream);
+    if (rc) return rc;
+    rc = gpsr_fit(w.X, w.y, bn, n, 8, kernel_id, raw + 4 * b0, iters, lr, w.alpha, nullptr, flags + b0, w.fit,
+                  fit_bytes, stream);
+    if (rc) return rc;
+    rc = gpsr_predict(w.X, w.Xs, w.alpha, raw + 4 * b0, bn, n, m, kernel_id, w.pred + (size_t)b0 * m, stream);
+    if (rc) return rc;
+  }
+  return gpsr_combine(w.pred, test_in, H, W, s, p, rows, nr, cols, nc, mode, 1, out, stream);
+}
+
 // ---------------------------------------------------------------- AGPR
 extern "C" int gpsr_agpr_weights(const double* X, const double* alpha, const float* raw, int n, int d,
                                  double* w, void* stream) {

@@ -97,6 +97,15 @@ __device__ __forceinline__ int xcd_remap(int bid, int total) {
   return base + s;
 }
 
+// locs[b] = (rows[b / nc], cols[b % nc]): PatchHandler.patch_locations order (image_patches.py:31-41)
+__global__ void k_make_locs(const int* __restrict__ rows, const int* __restrict__ cols, int nr, int nc,
+                            int* __restrict__ locs) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= nr * nc) return;
+  locs[2 * b] = rows[b / nc];
+  locs[2 * b + 1] = cols[b % nc];
+}
+
 // ---------------------------------------------------------------- K1 gather
 __global__ void k_gather(const double* __restrict__ tin, const double* __restrict__ ttg,
                          const double* __restrict__ tst, int H, int W, int s, int p,

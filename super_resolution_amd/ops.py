@@ -140,6 +140,27 @@ def combine(pred, test_in, H, W, s, p, rows, cols, mode=AVERAGE, clip=True):
     return out
 
 
+def predict_pixels_fused(train_in, train_tgt, test_in, s, p, rows, cols, tidx, kernel_id, init_raw_os=0.0,
+                         init_raw_ls=0.0, iters=50, lr=0.1, mode=AVERAGE, chunk=0):
+    """One-call GPRSR.predict_pixels for one image (gpsr_predict_pixels) -> out [H*s,W*s], raw [B,4], flags [B]."""
+    lib = _lib.load()
+    H, W = train_in.shape
+    nr, nc, nt = rows.numel(), cols.numel(), tidx.numel()
+    B = nr * nc
+    dev = train_in.device
+    nbytes = lib.gpsr_predict_pixels_workspace_bytes(s, p, nt, B, chunk)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+    out = torch.empty((H * s, W * s), dtype=torch.float64, device=dev)
+    raw = torch.empty((B, 4), dtype=torch.float32, device=dev)
+    flags = torch.empty(B, dtype=torch.int32, device=dev)
+    _lib.check(lib.gpsr_predict_pixels(_p(train_in, torch.float64), _p(train_tgt, torch.float64),
+                                       _p(test_in, torch.float64), H, W, s, p, _p(rows, torch.int32), nr,
+                                       _p(cols, torch.int32), nc, _p(tidx, torch.int32), nt, kernel_id,
+                                       float(init_raw_os), float(init_raw_ls), iters, float(lr), mode, chunk,
+                                       _p(out), _p(raw), _p(flags), _p(ws), nbytes, _stream()), "gpsr_predict_pixels")
+    return out, raw, flags
+
+
 def agpr_weights(X, alpha, raw):
     lib = _lib.load()
     n, d = X.shape

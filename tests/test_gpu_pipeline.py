@@ -209,3 +209,26 @@ def test_loose_pin_against_the_references_own_output(golden_dir):
     assert cvops.psnr(ref, got) > 45.0                       # measured 46.8 dB between the two outputs
     c = 3
     assert abs(cvops.psnr(hr[c:-c, c:-c], got[c:-c, c:-c]) - cvops.psnr(hr[c:-c, c:-c], ref[c:-c, c:-c])) < 0.03
+
+
+@pytest.mark.parametrize("kid,s,chunk", [(3, 2, 0), (0, 3, 3), (2, 2, 4)])
+def test_fused_predict_pixels_entry_point_equals_staged_path(kid, s, chunk):
+    """gpsr_predict_pixels (one C call: gather -> init -> fit -> predict -> combine, chunked)
+    gives the same bits as the staged engine path, and stays within the oracle bar."""
+    from super_resolution_amd import engine, ops
+    H, W, p = 47, 44, 10 * s
+    lr = natural_image(H, W, 21 + kid)
+    hi = cvops.resize_cubic(lr, fx=s, fy=s)
+    tin, tst = to_dev(lr), to_dev(hi)
+    gp = engine.BatchedGP(kid)
+    staged = engine.predict_pixels_batch([(tin, tin, tst)], s, p, gp)[0]
+    rows, cols, _ = engine._geometry(H, W, s, p, 0.9)
+    tidx = engine.training_indices(p)
+    fused, raw, flags = ops.predict_pixels_fused(tin, tin, tst, s, p, to_dev(np.asarray(rows, np.int32)),
+                                                 to_dev(np.asarray(cols, np.int32)), to_dev(tidx), kid, chunk=chunk)
+    assert int(flags.sum()) == 0
+    assert torch.equal(fused, staged)
+    o = osr.OracleGPRSR(s, kid, "GRAYSCALE", chain=False)
+    o.current_scaling_factor = s
+    want = o.predict_pixels(lr, lr, hi)
+    assert np.abs(fused.cpu().numpy() - want).max() < 2e-3 / 255
