@@ -98,6 +98,21 @@ def cpu_baseline(kernel_id, s, seconds_budget=20.0):
     return dt / done, done, cores
 
 
+def pmc_traffic(workload, B_local, N):
+    """HBM bytes per k_update launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
+    correction of MI355X_MICROARCH.md, + WRITE_SIZE), which were taken on 633 GPs of order 784 = this bench's
+    default shape.  Counters cannot be read from inside this process: None for any other shape or if the
+    summary is absent."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_invert_633x784.json")
+    if workload != "set14x3" or B_local != 633 or N != 784 or not os.path.exists(path):
+        return None
+    try:
+        with open(path) as f:
+            return round(json.load(f)["k_update_hbm_bytes_per_launch"]["traffic_corrected"])
+    except (KeyError, ValueError):
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -174,7 +189,9 @@ def main():
     kernel_ms = {k: round(v[1] / a.steps, 3) for k, v in prof.items()}
     roofline = {"kernel": "k_update", "bound": "mfma", "achieved": round(achieved, 3),
                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                "traffic": None, "launches_per_step": cnt // max(1, a.steps), "avg_launch_ms": round(avg_s * 1e3, 4),
+                "traffic": pmc_traffic(a.workload, B_local, N),
+                "traffic_note": "HBM bytes per launch, profiles/r01_pmc_invert_633x784.json (separate rocprofv3 --pmc passes)",
+                "launches_per_step": cnt // max(1, a.steps), "avg_launch_ms": round(avg_s * 1e3, 4),
                 "flops_per_launch": flops_launch, "kernel_ms_per_step": kernel_ms}
 
     cpu = None
