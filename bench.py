@@ -195,7 +195,7 @@ def main():
                 "flops_per_launch": flops_launch, "kernel_ms_per_step": kernel_ms}
 
     cpu = None
-    if not a.no_cpu_baseline:
+    if not a.no_cpu_baseline and world == 1:   # reported at N=1 only (rank 0 would stall the other ranks' exit)
         sec_per_fit, nfit, cores = cpu_baseline(g._gp.kernel_id, s)
         fits = 2 * n_patches // world  # per copy of the workload
         cpu_val = (out_px / world) / 1e6 / (sec_per_fit * fits)

@@ -20,9 +20,10 @@ def shard_range(B, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def all_gather_rows(local, B, world, group=None):
-    """local: this rank's [hi-lo, ...] slice (shard_range order) -> the full [B, ...] tensor on every rank."""
-    if world == 1:
+def all_gather_rows(local, B, world, group=None, force_collective=False):
+    """local: this rank's [hi-lo, ...] slice (shard_range order) -> the full [B, ...] tensor on every rank.
+    force_collective: run the collective even for world == 1 (used by the single-GPU RCCL smoke test)."""
+    if world == 1 and not force_collective:
         return local
     cap = (B + world - 1) // world
     tail = local.shape[1:]

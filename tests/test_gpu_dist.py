@@ -1,0 +1,41 @@
+"""RCCL smoke test on the one GPU of the box: a 1-rank "nccl" process group running the
+same collective calls the sharded path makes (dist.all_gather of the padded f64 / f32 /
+int32 slices).  The world-2 logic itself is covered on CPU with gloo (tests/test_host.py);
+8-GPU runs are the driver's."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+CHILD = r"""
+import os, sys
+sys.path.insert(0, %r)
+import torch, torch.distributed as dist
+from super_resolution_amd import dist as gdist
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT="29653", RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+torch.cuda.set_device(0)
+dist.init_process_group(backend="nccl", rank=0, world_size=1)
+dev = torch.device("cuda", 0)
+g = torch.Generator(device=dev); g.manual_seed(1)
+pred = torch.randn((37, 1444), dtype=torch.float64, device=dev, generator=g)
+raw = torch.randn((37, 4), dtype=torch.float32, device=dev, generator=g)
+flags = torch.arange(37, dtype=torch.int32, device=dev)
+for t in (pred, raw, flags):
+    out = gdist.all_gather_rows(t, 37, 1, force_collective=True)
+    assert out.shape == t.shape and torch.equal(out, t)
+dist.barrier()
+torch.cuda.synchronize()
+dist.destroy_process_group()
+sys.stdout.write("rccl-ok\n")
+"""
+
+
+@pytest.mark.gpu
+def test_rccl_all_gather_single_rank():
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]

@@ -1,0 +1,68 @@
+// Inner loop of k_update in isolation: operands resident in LDS (no global traffic at all),
+// 7 waves x (16x112 strip = 7 accumulators), 16-deep chunks, optional barrier per chunk.
+// Tells how much of the f64 MFMA peak the LDS-fed loop itself can reach.
+#include <hip/hip_runtime.h>
+#include <cstdio>
+typedef double v4d __attribute__((ext_vector_type(4)));
+#define NB 112
+#define KC 16
+
+template <int WAVES, bool BARRIER, int NACC>
+__global__ void __launch_bounds__(64 * WAVES, 4) k_loop(double* out, int chunks) {
+  __shared__ double lds[4 * KC * NB];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int e = tid; e < 4 * KC * NB; e += 64 * WAVES) lds[e] = 1e-3 * (e % 97);
+  __syncthreads();
+  v4d acc[NACC];
+#pragma unroll
+  for (int t = 0; t < NACC; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int ch = 0; ch < chunks; ++ch) {
+    const double* As = lds + (ch & 1) * 2 * KC * NB;
+    const double* Bs = As + KC * NB;
+    if (BARRIER) __syncthreads();
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      const int row = (ks * 4 + lk) * NB;
+      const double av = As[row + 16 * (wave % 7) + lr];
+#pragma unroll
+      for (int t = 0; t < NACC; ++t) {
+        const double bv = Bs[row + 16 * t + lr];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int t = 0; t < NACC; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+  if (s == 12345.678) out[0] = s;
+}
+
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+template <int WAVES, bool BARRIER, int NACC>
+int run(double* out, const char* name) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int chunks = 700, grid = 256 * 2 * 8;
+  hipLaunchKernelGGL((k_loop<WAVES, BARRIER, NACC>), dim3(grid), dim3(64 * WAVES), 0, 0, out, 7);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL((k_loop<WAVES, BARRIER, NACC>), dim3(grid), dim3(64 * WAVES), 0, 0, out, chunks);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)grid * WAVES * chunks * 4 * NACC * 2048.0;
+  printf("%-34s %.3f ms  %.1f TFLOP/s\n", name, ms, flops / ms * 1e-9);
+  return 0;
+}
+
+int main() {
+  double* out; CK(hipMalloc(&out, 8));
+  run<7, true, 7>(out, "7 waves, barrier/chunk, 7 acc");
+  run<7, false, 7>(out, "7 waves, no barrier, 7 acc");
+  run<4, true, 7>(out, "4 waves, barrier/chunk, 7 acc");
+  run<4, false, 7>(out, "4 waves, no barrier, 7 acc");
+  run<8, true, 7>(out, "8 waves, barrier/chunk, 7 acc");
+  run<8, false, 7>(out, "8 waves, no barrier, 7 acc");
+  return 0;
+}
