@@ -160,7 +160,10 @@ static InvWs inv_ws_carve(char* base, int B, int N) {
 }
 
 // sweeps every pivot block of B matrices; logdet must have been zeroed
-static int launch_sweeps(double* A, int B, int N, const InvWs& w, double* logdet, int32_t* flags, hipStream_t st) {
+// y / raw / part non-null: the last update launch also leaves the mat-vec partials of
+// alpha = K^-1 (y - c) (grad1_partials), n = number of real rows.
+static int launch_sweeps(double* A, int B, int N, const InvWs& w, double* logdet, int32_t* flags, hipStream_t st,
+                         const double* y = nullptr, const float* raw = nullptr, int n = 0, double* part = nullptr) {
   const int nblk = N / NB;
   static bool lds_attr_set = false;
   if (!lds_attr_set) {
@@ -182,7 +185,13 @@ static int launch_sweeps(double* A, int B, int N, const InvWs& w, double* logdet
       CHECK_LAUNCH("k_panel");
       const int ntri1 = (nblk - 1) * nblk / 2, tu = (ntri1 + nblk - 1) * B;
       pr = prof_start(T_UPDATE, st);
-      hipLaunchKernelGGL(k_update, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M, ntri1, tu);
+      const bool last = (k == nblk - 1) && part;
+      if (last)
+        hipLaunchKernelGGL(k_update<true>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M, ntri1, tu,
+                           y, raw, n, part);
+      else
+        hipLaunchKernelGGL(k_update<false>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M, ntri1, tu,
+                           (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr);
       prof_stop(pr, st);
       CHECK_LAUNCH("k_update");
     }
@@ -212,12 +221,18 @@ extern "C" int gpsr_invert(double* A, int B, int n, double* logdet, int32_t* fla
 
 // ---------------------------------------------------------------- fit
 struct FitWs {
-  double* A; InvWs inv; double *stats1, *stats2, *logdet; float *m1, *m2;
+  double* A; InvWs inv; double *stats1, *stats2, *logdet, *part; float *m1, *m2;
 };
+// per-tile mat-vec partials of the last update launch: [B][ntri(nblk-1) + nblk-1][2][NB]
+static size_t part_bytes(int B, int nblk) {
+  const int per = (nblk - 1) * nblk / 2 + nblk - 1;
+  return align256((size_t)B * (per > 0 ? per : 1) * 2 * NB * 8);
+}
 static size_t fit_ws_bytes(int B, int N) {
   const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2;
   return align256((size_t)B * N * N * 8) + inv_ws_bytes(B, N) + align256((size_t)B * nblk * 4 * 8) +
-         align256((size_t)B * ntri * 2 * 8) + align256((size_t)B * 8) + 2 * align256((size_t)B * 4 * 4);
+         align256((size_t)B * ntri * 2 * 8) + align256((size_t)B * 8) + part_bytes(B, nblk) +
+         2 * align256((size_t)B * 4 * 4);
 }
 static FitWs fit_ws_carve(char* base, int B, int N) {
   const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2;
@@ -227,6 +242,7 @@ static FitWs fit_ws_carve(char* base, int B, int N) {
   w.stats1 = (double*)base; base += align256((size_t)B * nblk * 4 * 8);
   w.stats2 = (double*)base; base += align256((size_t)B * ntri * 2 * 8);
   w.logdet = (double*)base; base += align256((size_t)B * 8);
+  w.part = (double*)base; base += part_bytes(B, nblk);
   w.m1 = (float*)base; base += align256((size_t)B * 4 * 4);
   w.m2 = (float*)base;
   return w;
@@ -266,12 +282,19 @@ static int eval_once(const FitWs& w, const double* X, const double* y, const flo
                      int32_t* flags, int B, int n, int N, int d, int kid, bool with_grad, hipStream_t st) {
   int rc = launch_build(X, B, n, N, d, kid, raw, w.A, w.logdet, st);
   if (rc) return rc;
-  rc = launch_sweeps(w.A, B, N, w.inv, w.logdet, flags, st);
-  if (rc) return rc;
   const int nblk = N / NB;
-  const size_t lds1 = (size_t)(N + 5 * NB + 32) * sizeof(double);
+  const bool fused = nblk > 1;   // alpha's mat-vec rides on the last update launch; one block: nothing to ride on
+  rc = fused ? launch_sweeps(w.A, B, N, w.inv, w.logdet, flags, st, y, raw, n, w.part)
+             : launch_sweeps(w.A, B, N, w.inv, w.logdet, flags, st);
+  if (rc) return rc;
   ProfRec* pr = prof_start(T_GRAD1, st);
-  hipLaunchKernelGGL(k_grad1, dim3(nblk, B), dim3(MM_THREADS), lds1, st, w.A, N, n, nblk, y, raw, alpha, w.stats1);
+  if (fused) {
+    hipLaunchKernelGGL(k_grad1r, dim3(nblk, B), dim3(MM_THREADS), 0, st, w.A, N, n, nblk, nblk - 1, y, raw, w.part,
+                       (nblk - 1) * nblk / 2, alpha, w.stats1);
+  } else {
+    const size_t lds1 = (size_t)(N + 5 * NB + 32) * sizeof(double);
+    hipLaunchKernelGGL(k_grad1, dim3(nblk, B), dim3(MM_THREADS), lds1, st, w.A, N, n, nblk, y, raw, alpha, w.stats1);
+  }
   prof_stop(pr, st);
   CHECK_LAUNCH("k_grad1");
   if (with_grad) return launch_grad2(w, X, raw, alpha, B, n, N, d, kid, st);

@@ -695,9 +695,66 @@ __device__ __forceinline__ void tile_product_dma_latec(const double* __restrict_
   }
 }
 
+// ---- alpha = K^-1 (y - c) without re-reading the inverse -------------------------------
+// At the last pivot step every tile of -K^-1 except the pivot block is final in the
+// accumulators of k_update.  Each workgroup leaves the two mat-vec partials of its tile,
+//   part[0][r] = sum_c T[r][c] r_J[c]   (-> rows of block I)
+//   part[1][c] = sum_r T[r][c] r_I[r]   (-> rows of block J, by symmetry; for a diagonal
+//                tile: the blocks left of the diagonal only, and the target is block I too)
+// and k_grad1r adds them up in a fixed order.  acc[t][rr] = T[16 wave + lk + 4 rr][16 t + lr].
+#define G1_COLBUF (NBT * 16 * 17)   // doubles: behind the per-wave transposition scratch
+__device__ __forceinline__ void grad1_partials(const v4d acc[NBT], bool diag, const double* __restrict__ yb,
+                                               double mean, int n, int I, int J, double* __restrict__ lds,
+                                               double* __restrict__ part, int wave, int lane, int tid) {
+  const int lr = lane & 15, lk = lane >> 4;
+  double rI[4], rJ[NBT];
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    const int gi = I * NB + 16 * wave + lk + 4 * rr;
+    rI[rr] = gi < n ? yb[gi] - mean : 0.0;
+  }
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) {
+    const int gj = J * NB + 16 * t + lr;
+    rJ[t] = gj < n ? yb[gj] - mean : 0.0;
+  }
+#pragma unroll
+  for (int rr = 0; rr < 4; ++rr) {
+    double p = 0.0;
+#pragma unroll
+    for (int t = 0; t < NBT; ++t)
+      if (!diag || t <= wave) p = fma(acc[t][rr], rJ[t], p);
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1) p += __shfl_xor(p, o);
+    if (lr == 0) part[16 * wave + lk + 4 * rr] = p;
+  }
+  double* cb = lds + G1_COLBUF + wave * NB;
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) {
+    double q = 0.0;
+    if (!diag || t < wave) {
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) q = fma(acc[t][rr], rI[rr], q);
+    }
+    q += __shfl_xor(q, 16);
+    q += __shfl_xor(q, 32);
+    if (lk == 0) cb[16 * t + lr] = q;
+  }
+  __syncthreads();
+  if (tid < NB) {
+    double sacc = 0.0;
+#pragma unroll
+    for (int w = 0; w < NBT; ++w) sacc += lds[G1_COLBUF + w * NB + tid];
+    part[NB + tid] = sacc;
+  }
+}
+
+template <bool G1>   // G1: last pivot step of a fit evaluation, leaves the alpha mat-vec partials (own instantiation:
+                     // the epilogue's registers must not weigh on the six launches that do not need it)
 __global__ void __launch_bounds__(MM_THREADS, 4)
 k_update(double* __restrict__ A, int N, int nblk, int k,
-             const double* __restrict__ Wo, const double* __restrict__ Mbuf, int ntri1, int total) {
+             const double* __restrict__ Wo, const double* __restrict__ Mbuf, int ntri1, int total,
+             const double* __restrict__ y, const float* __restrict__ raw, int n, double* __restrict__ part) {
   __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int v = xcd_remap(blockIdx.x, total);
@@ -728,12 +785,19 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
       }
       __syncthreads();   // chunk buffers are free: per-wave transposition scratch
       store_strip_transposed(acc, Ab + (size_t)(I * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr, wave);
+      if (G1) grad1_partials(acc, true, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, I, lds,
+                               part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
     } else {
       tile_product_dma_latec(Aop, N, Bop, N, lds, acc, Ct, (size_t)N, wave, lane);
 #pragma unroll
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+      if (G1) {
+        __syncthreads();   // every wave is out of the chunk loop: the LDS buffers are free
+        grad1_partials(acc, false, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, J, lds,
+                       part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
+      }
     }
   } else {
     int I = t0 - ntri1; if (I >= k) ++I;
@@ -751,6 +815,11 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
     } else {
       __syncthreads();
       store_strip_transposed(acc, Ab + (size_t)(k * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr);
+    }
+    if (G1) {
+      __syncthreads();
+      grad1_partials(acc, false, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, k, lds,
+                     part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
     }
   }
 }
@@ -812,6 +881,66 @@ k_grad1(const double* __restrict__ A, int N, int n, int nblk, const double* __re
   }
   __syncthreads();
   if (tid < 4) stats1[((size_t)b * nblk + I) * 4 + tid] = red[tid] + red[4 + tid];
+}
+
+// ------------------------------------------------------------------ grad1 (reduce form)
+// grid (nblk, B), 448 threads: same outputs as k_grad1 (alpha, stats1), from the per-tile
+// mat-vec partials the last k_update launch left (grad1_partials) plus the pivot block of
+// that step, the one tile k_update does not own.  Fixed summation order: deterministic.
+__global__ void __launch_bounds__(MM_THREADS)
+k_grad1r(const double* __restrict__ A, int N, int n, int nblk, int k, const double* __restrict__ y,
+         const float* __restrict__ raw, const double* __restrict__ part, int ntri1,
+         double* __restrict__ alpha, double* __restrict__ stats1) {
+  __shared__ double rk[NB];
+  __shared__ double pk[4][NB];
+  __shared__ double red[8 * 4];
+  const int R = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int per = ntri1 + nblk - 1;
+  const double mean = (double)raw[4 * b + 1];
+  const double* yb = y + (size_t)b * n;
+  const double* Ab = A + (size_t)b * N * N;
+  const double* pb = part + (size_t)b * per * (2 * NB);
+  if (R == k) {   // pivot block: alpha_k += A_kk r_k  (A_kk symmetric, both triangles stored: read columns, coalesced)
+    if (tid < NB) { const int gj = k * NB + tid; rk[tid] = gj < n ? yb[gj] - mean : 0.0; }
+    __syncthreads();
+    const int c = tid % NB, g = tid / NB;
+    const double* Akk = Ab + (size_t)(k * NB) * N + k * NB;
+    double sacc = 0.0;
+    for (int j = g; j < NB; j += 4) sacc = fma(Akk[(size_t)j * N + c], rk[j], sacc);
+    pk[g][c] = sacc;
+    __syncthreads();
+  }
+  double st[4] = {0.0, 0.0, 0.0, 0.0};
+  if (tid < NB) {
+    double sacc = (R == k) ? (pk[0][tid] + pk[1][tid]) + (pk[2][tid] + pk[3][tid]) : 0.0;
+    for (int t0 = 0; t0 < per; ++t0) {
+      int I, J;
+      if (t0 < ntri1) { tri_decode(t0, I, J); if (I >= k) ++I; if (J >= k) ++J; }
+      else { I = t0 - ntri1; if (I >= k) ++I; J = k; }
+      const double* pt = pb + (size_t)t0 * (2 * NB);
+      if (I == R) sacc += pt[tid];
+      if ((I == J ? I : J) == R) sacc += pt[NB + tid];
+    }
+    const int gi = R * NB + tid;
+    const double al = gi < n ? -sacc : 0.0;
+    alpha[(size_t)b * N + gi] = al;
+    if (gi < n) {
+      const double ri = yb[gi] - mean;
+      st[0] = -Ab[(size_t)gi * N + gi];
+      st[1] = al * al; st[2] = al * ri; st[3] = al;
+    }
+  }
+  if (tid < 128) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      double sacc = st[u];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) sacc += __shfl_xor(sacc, o);
+      if (lane == 0) red[wave * 4 + u] = sacc;
+    }
+  }
+  __syncthreads();
+  if (tid < 4) stats1[((size_t)b * nblk + R) * 4 + tid] = red[tid] + red[4 + tid];
 }
 
 // ------------------------------------------------------------------ grad2
