@@ -176,7 +176,8 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     value = out_px / 1e6 / (dt / a.steps)
 
-    # roofline of the dominant kernel: k_update = batched 112x112x112 f64 MFMA tile products.
+    # roofline of the dominant kernel: k_update<false> = batched 112x112x112 f64 MFMA tile products (the last pivot
+    # step of each evaluation runs k_update<true>, same products + the alpha epilogue: listed as "update_last").
     # Algorithmic flops of one launch (pivot step of B GPs): the symmetric trailing update
     # (N-NB)^2*NB plus the triangular pivot-column product W*L^-1, (N-NB)*NB^2.
     n = (10 * s - 2) ** 2
@@ -187,7 +188,7 @@ def main():
     avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
     achieved = flops_launch / avg_s / 1e12 if cnt else float("nan")
     kernel_ms = {k: round(v[1] / a.steps, 3) for k, v in prof.items()}
-    roofline = {"kernel": "k_update", "bound": "mfma", "achieved": round(achieved, 3),
+    roofline = {"kernel": "k_update<false>", "bound": "mfma", "achieved": round(achieved, 3),
                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
                 "traffic": pmc_traffic(a.workload, B_local, N),
                 "traffic_note": "HBM bytes per launch, profiles/r01_pmc_invert_633x784.json (separate rocprofv3 --pmc passes)",

@@ -219,7 +219,9 @@ int gpsr_axpy(const double* a, const double* b, double alpha, double* dst, size_
  */
 enum {
   GPSR_PROF_UPDATE = 0, GPSR_PROF_PANEL, GPSR_PROF_PIVOT, GPSR_PROF_BUILD,
-  GPSR_PROF_GRAD1, GPSR_PROF_GRAD2, GPSR_PROF_PREDICT, GPSR_PROFILE_NTAGS
+  GPSR_PROF_GRAD1, GPSR_PROF_GRAD2, GPSR_PROF_PREDICT,
+  GPSR_PROF_UPDATE_LAST, /* k_update<true>: the last pivot step's launch, which also leaves the alpha partials */
+  GPSR_PROFILE_NTAGS
 };
 int gpsr_profile_begin(int max_records);
 int gpsr_profile_end(int32_t* counts, double* total_ms);

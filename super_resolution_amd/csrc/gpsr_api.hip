@@ -29,7 +29,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Optional HIP-event brackets around tagged launches, on the stream the kernel is
 // launched on.  Off by default; costs two hipEventRecord per tagged launch when on.
 #include <vector>
-enum { T_UPDATE = 0, T_PANEL, T_PIVOT, T_BUILD, T_GRAD1, T_GRAD2, T_PREDICT, T_NTAGS };
+enum { T_UPDATE = 0, T_PANEL, T_PIVOT, T_BUILD, T_GRAD1, T_GRAD2, T_PREDICT, T_UPDATE_LAST, T_NTAGS };
 struct ProfRec { hipEvent_t a, b; int tag; };
 static std::vector<ProfRec> g_prof;
 static size_t g_prof_used = 0;
@@ -184,8 +184,8 @@ static int launch_sweeps(double* A, int B, int N, const InvWs& w, double* logdet
       prof_stop(pr, st);
       CHECK_LAUNCH("k_panel");
       const int ntri1 = (nblk - 1) * nblk / 2, tu = (ntri1 + nblk - 1) * B;
-      pr = prof_start(T_UPDATE, st);
       const bool last = (k == nblk - 1) && part;
+      pr = prof_start(last ? T_UPDATE_LAST : T_UPDATE, st);
       if (last)
         hipLaunchKernelGGL(k_update<true>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M, ntri1, tu,
                            y, raw, n, part);

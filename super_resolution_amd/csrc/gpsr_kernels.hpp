@@ -21,7 +21,6 @@
 #define NBT 7           // NB / 16 : MFMA tiles per edge == waves per workgroup
 #define MM_THREADS 448  // 64 * NBT
 #define KC 16           // k-chunk staged through LDS
-#define LDS_LD 113      // padded leading dimension of staged chunks
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -464,76 +463,14 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
 #define PIVOT_LDS_BYTES ((PV_NBLK * PV_BLK + NBT * PV_BLK) * sizeof(double))
 
 
-// ------------------------------------------------- shared MFMA tile product
-// acc[t] (16 rows of this wave x 16 cols of tile t) += sum_kk Aop[kk][16*wave + .] * Bop[kk][16*t + .]
-// over kk in [0, NB).  Aop/Bop are "k-major" sources: element (kk, c) at ptr[kk*ld + c];
-// if TRANS_A, Aop is row-major instead: element (kk, c) at ptr[c*ld + kk].
-// Staged through LDS in chunks of KC with register prefetch of the next chunk.
-// SKIP: Bop is block-triangular at 16x16 granularity, skip the zero products:
+// ------------------------------------------------- shared MFMA tile-product pieces
+// Tile products accumulate acc[t] (16 rows of this wave x 16 cols of block t) over kk in
+// [0, NB) from "k-major" LDS chunk images (element (kk, c) at [kk*NB + c]) that arrive by
+// global_load_lds.  SKIP: the B operand is block-triangular at 16x16 granularity, the zero
+// products are skipped:
 //   SKIP_UPPER  Bop[kk][c] == 0 unless tile(c) >= chunk(kk)
 //   SKIP_LOWER  Bop[kk][c] == 0 unless tile(c) <= chunk(kk)
 enum { SKIP_NONE = 0, SKIP_UPPER = 1, SKIP_LOWER = 2, SKIP_DIAG = 3 };   // SKIP_DIAG: symmetric result, wave w computes blocks t <= w only
-struct Stage { double a[4]; double b[4]; };
-
-template <bool TRANS_A>
-__device__ __forceinline__ void stage_load(Stage& s, const double* __restrict__ Aop, int lda,
-                                           const double* __restrict__ Bop, int ldb, int chunk, int tid) {
-  const int idx = tid * 4;
-  if (!TRANS_A) {
-    const int kk = idx / NB, c = idx % NB;
-    const double* p = Aop + (size_t)(chunk * KC + kk) * lda + c;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) s.a[u] = p[u];
-  } else {
-    const int r = idx / KC, kq = idx % KC;
-    const double* p = Aop + (size_t)r * lda + chunk * KC + kq;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) s.a[u] = p[u];
-  }
-  {
-    const int kk = idx / NB, c = idx % NB;
-    const double* p = Bop + (size_t)(chunk * KC + kk) * ldb + c;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) s.b[u] = p[u];
-  }
-}
-
-template <bool TRANS_A>
-__device__ __forceinline__ void stage_store(const Stage& s, double* __restrict__ As, double* __restrict__ Bs, int tid) {
-  const int idx = tid * 4;
-  if (!TRANS_A) {
-    const int kk = idx / NB, c = idx % NB;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) As[kk * LDS_LD + c + u] = s.a[u];
-  } else {
-    const int r = idx / KC, kq = idx % KC;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) As[(kq + u) * LDS_LD + r] = s.a[u];
-  }
-  {
-    const int kk = idx / NB, c = idx % NB;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) Bs[kk * LDS_LD + c + u] = s.b[u];
-  }
-}
-
-template <int SKIP>
-__device__ __forceinline__ void chunk_mfma(const double* __restrict__ As, const double* __restrict__ Bs,
-                                           v4d acc[NBT], int wave, int lane, int ch) {
-  const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-  for (int ks = 0; ks < KC / 4; ++ks) {
-    const int row = (ks * 4 + lk) * LDS_LD;
-    const double av = As[row + 16 * wave + lr];
-#pragma unroll
-    for (int t = 0; t < NBT; ++t) {
-      if (SKIP == SKIP_UPPER && t < ch) continue;
-      if (SKIP == SKIP_LOWER && t > ch) continue;
-      const double bv = Bs[row + 16 * t + lr];
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
-    }
-  }
-}
 
 // store a wave's 16x112 accumulator strip transposed: dst[(16*t + col) * ld + 16*wave + row] = sign*acc
 // (per-wave 16x17 LDS scratch; the staging buffers must be free)
@@ -560,52 +497,14 @@ __device__ __forceinline__ void store_strip_transposed(const v4d acc[NBT], doubl
   }
 }
 
-// ------------------------------------------------------------------ panel
-// grid.x = (nblk-1) * B.  For row block i != k, T = A_ik (block (i,k) row-major when i > k,
-// block (k,i) = T^T, i.e. k-major, when i < k):
-//   W = T L^-T = T U :  acc[r][k'] = sum_kk T[r][kk] U[kk][k']   (U upper: SKIP_UPPER)
-//   Wo[k'][i0+r] = W     (k-major panel for the update)
-__global__ void __launch_bounds__(MM_THREADS, 4)
-k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Ubuf,
-        double* __restrict__ Wo, int total) {
-  __shared__ double lds[2 * KC * LDS_LD];
-  double* As = lds; double* Bs = lds + KC * LDS_LD;
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int v = xcd_remap(blockIdx.x, total);
-  const int b = v / (nblk - 1);
-  int i = v % (nblk - 1); if (i >= k) ++i;
-  const double* Ab = A + (size_t)b * N * N;
-  const double* U = Ubuf + (size_t)b * NB * NB;
-  const int i0 = i * NB, k0 = k * NB;
-  const bool below = i > k;
-  const double* Tsrc = below ? Ab + (size_t)i0 * N + k0 : Ab + (size_t)k0 * N + i0;
-  v4d acc[NBT];
-#pragma unroll
-  for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-  Stage st;
-  if (below) stage_load<true>(st, Tsrc, N, U, NB, 0, tid); else stage_load<false>(st, Tsrc, N, U, NB, 0, tid);
-  for (int ch = 0; ch < NB / KC; ++ch) {
-    __syncthreads();
-    if (below) stage_store<true>(st, As, Bs, tid); else stage_store<false>(st, As, Bs, tid);
-    __syncthreads();
-    if (ch + 1 < NB / KC) {
-      if (below) stage_load<true>(st, Tsrc, N, U, NB, ch + 1, tid); else stage_load<false>(st, Tsrc, N, U, NB, ch + 1, tid);
-    }
-    chunk_mfma<SKIP_UPPER>(As, Bs, acc, wave, lane, ch);
-  }
-  __syncthreads();
-  // acc[t][rr] = W[r = 16*wave + lk + 4rr][k' = 16t + lr]  ->  Wo[k'][i0 + r]
-  store_strip_transposed(acc, Wo + (size_t)b * NB * N + i0, (size_t)N, lds, wave, lane, 1.0, nullptr);
-}
-
 // ----------------------------------------------------------------- update
 // grid.x = (ntri(nblk-1) + nblk-1) * B.  Two kinds of 112x112 tile products:
 //   trailing tile (I,J), I >= J, I,J != k:   A_IJ -= W_I W_J^T      (Aop = -Wo_I, Bop = Wo_J)
 //   pivot-column tile I != k:                A_Ik  = W_I L^-1 = W_I M (Aop = Wo_I, Bop = M lower: SKIP_LOWER)
 //     stored row-major into block (I,k) when I > k, transposed into block (k,I) when I < k.
 // The 16-deep operand chunks go global -> LDS directly (global_load_lds_dwordx4: no VGPR
-// staging, no LDS store pass), double-buffered, one barrier per chunk (9 % faster than
-// the register-staged loop the panel kernel still uses for its transposed operand).  LDS image of a chunk = [16][112] doubles, unpadded (the DMA writes
+// staging, no LDS store pass), double-buffered, one barrier per chunk (9 % faster than a
+// register-staged loop).  LDS image of a chunk = [16][112] doubles, unpadded (the DMA writes
 // wave-uniform base + lane*16 B, so the image must be lane-linear); the MFMA operand reads
 // (16 consecutive doubles per 16-lane group, rows 896 B apart) are bank-conflict free.
 #define DMA_CHUNK (KC * NB)  // doubles per operand chunk
@@ -822,6 +721,84 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
                      part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
     }
   }
+}
+
+// ------------------------------------------------------------------ panel
+// grid.x = (nblk-1) * B.  For row block i != k, T = A_ik:  W = T L^-T = T U, stored k-major,
+// Wo[k'][i0 + r] = W[r][k'].  Wave w owns rows [16w, 16w+16) of the tile; U is upper
+// block-triangular (blocks t >= chunk).  Both operands arrive by global_load_lds
+// (double-buffered, one barrier per chunk):
+//   B operand  U   : the chunk [16 kk][112 k'] as it lies in memory
+//   A operand  T   : i < k -> block (k,i) holds T^T: chunk [16 kk][112 r] as it lies (k-major);
+//                    i > k -> block (i,k) holds T row-major: the chunk is 112 rows x 128 B.
+//                             The DMA writes LDS lane-linearly but each lane picks its own 16 B
+//                             of global memory, so the 16-byte units of a row are stored
+//                             XOR-swizzled (unit u of row r at slot 8r + (u ^ ((r>>1)&7))):
+//                             the MFMA A reads (16 lanes = 16 rows, same kk) are conflict-free.
+__device__ __forceinline__ void dma_chunk_panel(const double* __restrict__ Tsrc, size_t N, bool below,
+                                                const double* __restrict__ U, int chunk, double* __restrict__ bufA,
+                                                double* __restrict__ bufB, int wave, int lane) {
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int piece = 2 * wave + u;
+    const int e = piece * 128 + lane * 2;
+    const int kk = e / NB, c = e % NB;
+    const double* gb = U + (size_t)(chunk * KC + kk) * NB + c;
+    const double* ga;
+    if (!below) ga = Tsrc + (size_t)(chunk * KC + kk) * N + c;
+    else {
+      const int slot = piece * 64 + lane, r = slot >> 3, j = slot & 7;
+      ga = Tsrc + (size_t)r * N + chunk * KC + 2 * (j ^ ((r >> 1) & 7));
+    }
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+                                     (__attribute__((address_space(3))) void*)(bufA + piece * 128), 16, 0, 0);
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+                                     (__attribute__((address_space(3))) void*)(bufB + piece * 128), 16, 0, 0);
+  }
+}
+
+__global__ void __launch_bounds__(MM_THREADS, 4)
+k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Ubuf,
+         double* __restrict__ Wo, int total) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int v = xcd_remap(blockIdx.x, total);
+  const int b = v / (nblk - 1);
+  int i = v % (nblk - 1); if (i >= k) ++i;
+  const double* Ab = A + (size_t)b * N * N;
+  const double* U = Ubuf + (size_t)b * NB * NB;
+  const int i0 = i * NB, k0 = k * NB;
+  const bool below = i > k;
+  const double* Tsrc = below ? Ab + (size_t)i0 * N + k0 : Ab + (size_t)k0 * N + i0;
+  v4d acc[NBT];
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  dma_chunk_panel(Tsrc, (size_t)N, below, U, 0, lds, lds + DMA_CHUNK, wave, lane);
+  const int r = 16 * wave + lr, rsw = (r >> 1) & 7;
+#pragma unroll
+  for (int ch = 0; ch < NB / KC; ++ch) {
+    const double* As = lds + (ch & 1) * 2 * DMA_CHUNK;
+    const double* Bs = As + DMA_CHUNK;
+    double* nxt = lds + ((ch + 1) & 1) * 2 * DMA_CHUNK;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (ch + 1 < NB / KC) dma_chunk_panel(Tsrc, (size_t)N, below, U, ch + 1, nxt, nxt + DMA_CHUNK, wave, lane);
+#pragma unroll
+    for (int ks = 0; ks < KC / 4; ++ks) {
+      const int kk = ks * 4 + lk;
+      const double av = below ? As[(r * 8 + ((kk >> 1) ^ rsw)) * 2 + (kk & 1)] : As[kk * NB + r];
+#pragma unroll
+      for (int t = 0; t < NBT; ++t) {
+        if (t < ch) continue;
+        const double bv = Bs[kk * NB + 16 * t + lr];
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();
+  // acc[t][rr] = W[r = 16*wave + lk + 4rr][k' = 16t + lr]  ->  Wo[k'][i0 + r]
+  store_strip_transposed(acc, Wo + (size_t)b * NB * N + i0, (size_t)N, lds, wave, lane, 1.0, nullptr);
 }
 
 // ------------------------------------------------------------------ grad1
