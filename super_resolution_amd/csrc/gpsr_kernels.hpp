@@ -271,7 +271,9 @@ __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, d
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int jr = j & 3, jc = j >> 2;
-    const double pv = __shfl(a[jc], j + 16 * jr);    // D[j][j]
+    // D[j][j]: lane index is a compile-time constant -> scalar broadcast (v_readlane), off the LDS crossbar
+    const double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[jc]), j + 16 * jr),
+                                       __builtin_amdgcn_readlane(__double2loint(a[jc]), j + 16 * jr));
     const double cl = __shfl(a[jc], lr + 16 * jr);   // D[j][lr]   (row j; used for lr > j)
     const double mj = __shfl(m[jc], lr + 16 * jr);   // M[j][lr]
     double ci[4];
@@ -319,12 +321,23 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   const int b = blockIdx.x, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   double* Akk = A + (size_t)b * N * N + (size_t)(k * NB) * N + k * NB;
-  for (int e = tid; e < PV_NBLK * 256; e += MM_THREADS) {
-    const int blk = e >> 8, r = (e >> 4) & 15, c = e & 15;
-    int bi = 0;
-    while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
-    const int bj = blk - bi * (bi + 1) / 2;
-    S[blk * PV_BLK + r * PV_DLD + c] = Akk[(size_t)(16 * bi + r) * N + 16 * bj + c];
+  // 28 blocks x 16 rows x 8 units of 16 B = 3584 units = 8 per thread: all 8 loads are issued
+  // before the first LDS store, so the block arrives in one memory latency instead of sixteen
+  {
+    double2 v[PV_NBLK * 128 / MM_THREADS];
+    int dst[PV_NBLK * 128 / MM_THREADS];
+#pragma unroll
+    for (int i = 0; i < PV_NBLK * 128 / MM_THREADS; ++i) {
+      const int u = tid + MM_THREADS * i;
+      const int blk = u >> 7, r = (u >> 3) & 15, c = (u & 7) * 2;
+      int bi = 0;
+      while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
+      const int bj = blk - bi * (bi + 1) / 2;
+      v[i] = *(const double2*)(Akk + (size_t)(16 * bi + r) * N + 16 * bj + c);
+      dst[i] = blk * PV_BLK + r * PV_DLD + c;
+    }
+#pragma unroll
+    for (int i = 0; i < PV_NBLK * 128 / MM_THREADS; ++i) { S[dst[i]] = v[i].x; S[dst[i] + 1] = v[i].y; }
   }
   __syncthreads();
   double ld = 0.0;
@@ -332,18 +345,20 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   double* tr = Tr + wave * PV_BLK;
   // ---------------- phase 1: blocked Cholesky; afterwards SB(q,q) = inv(L16_q), SB(w,q) = L[w,q]
   // The 16x16 factor+inverse is a serial register kernel: ONE wave (the owner of the diagonal
-  // block) runs it and publishes inv(L16_q) in place; the other workgroup resident on the CU
-  // fills the SIMDs meanwhile.
-  for (int q = 0; q < NBT; ++q) {
-    if (wave == q) {
-      double a[4], m[4];
+  // block) runs it and publishes inv(L16_q) in place.
+  // Look-ahead: the wave that owns diagonal block q+1 updates it with panel column q and factors
+  // it at once, in registers (the MFMA accumulator layout is chol16_inv's input layout), while
+  // the waves below finish their part of the trailing update of step q.
+  if (wave == 0) {
+    double a[4], m[4];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) a[c] = SB(q, q)[(lk + 4 * c) * PV_DLD + lr];
-      chol16_inv(a, m, lane, &ld, &bad);
+    for (int c = 0; c < 4; ++c) a[c] = SB(0, 0)[(lk + 4 * c) * PV_DLD + lr];
+    chol16_inv(a, m, lane, &ld, &bad);
 #pragma unroll
-      for (int c = 0; c < 4; ++c) SB(q, q)[(lk + 4 * c) * PV_DLD + lr] = m[c];
-    }
-    __syncthreads();
+    for (int c = 0; c < 4; ++c) SB(0, 0)[(lk + 4 * c) * PV_DLD + lr] = m[c];
+  }
+  __syncthreads();
+  for (int q = 0; q < NBT - 1; ++q) {
     if (wave > q) {
       // L_wq = S[w,q] * inv(L16)^T : B operand element (k, col) = inv(L16)[col][k]
       const double* Mqq = SB(q, q);
@@ -372,8 +387,17 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
 #pragma unroll
         for (int ks = 0; ks < 4; ++ks)
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(an[ks], Sjq[lr * PV_DLD + lk + 4 * ks], acc, 0, 0, 0);
+        if (wave == q + 1) {   // j == wave: the next diagonal block, final -> factor it now
+          double a[4], m[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) Swj[(lk + 4 * c) * PV_DLD + lr] = acc[c];
+          for (int c = 0; c < 4; ++c) a[c] = acc[c];
+          chol16_inv(a, m, lane, &ld, &bad);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Swj[(lk + 4 * c) * PV_DLD + lr] = m[c];
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) Swj[(lk + 4 * c) * PV_DLD + lr] = acc[c];
+        }
       }
     }
     __syncthreads();
@@ -447,13 +471,16 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   // The zero blocks are never written: the panel / update kernels skip the products that would read them.
   double* Ub = Ubuf + (size_t)b * NB * NB;
   double* Mb = Mbuf + (size_t)b * NB * NB;
-  for (int e = tid; e < PV_NBLK * 256; e += MM_THREADS) {
-    const int blk = e >> 8, r = (e >> 4) & 15, c = e & 15;
+#pragma unroll
+  for (int i = 0; i < PV_NBLK * 128 / MM_THREADS; ++i) {   // 16-byte units, as in the load
+    const int u = tid + MM_THREADS * i;
+    const int blk = u >> 7, r = (u >> 3) & 15, c = (u & 7) * 2;
     int bi = 0;
     while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
     const int bj = blk - bi * (bi + 1) / 2;
-    Mb[(16 * bi + r) * NB + 16 * bj + c] = S[blk * PV_BLK + r * PV_DLD + c];   // M[i][j]
-    Ub[(16 * bj + r) * NB + 16 * bi + c] = S[blk * PV_BLK + c * PV_DLD + r];   // U[j][i] = M[i][j]
+    const double* Sb = S + blk * PV_BLK;
+    *(double2*)(Mb + (16 * bi + r) * NB + 16 * bj + c) = make_double2(Sb[r * PV_DLD + c], Sb[r * PV_DLD + c + 1]);      // M[i][j]
+    *(double2*)(Ub + (16 * bj + r) * NB + 16 * bi + c) = make_double2(Sb[c * PV_DLD + r], Sb[(c + 1) * PV_DLD + r]);    // U[j][i] = M[i][j]
   }
   if (tid == 0) {
     logdet[b] += ld;
