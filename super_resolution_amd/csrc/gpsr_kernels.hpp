@@ -629,21 +629,25 @@ __device__ __forceinline__ void tile_product_dma_latec(const double* __restrict_
 //                tile: the blocks left of the diagonal only, and the target is block I too)
 // and k_grad1r adds them up in a fixed order.  acc[t][rr] = T[16 wave + lk + 4 rr][16 t + lr].
 #define G1_COLBUF (NBT * 16 * 17)   // doubles: behind the per-wave transposition scratch
-__device__ __forceinline__ void grad1_partials(const v4d acc[NBT], bool diag, const double* __restrict__ yb,
-                                               double mean, int n, int I, int J, double* __restrict__ lds,
-                                               double* __restrict__ part, int wave, int lane, int tid) {
+// rv: LDS, [0, NB) = r of row block I, [NB, 2NB) = r of column block J (staged at kernel start by grad1_stage_r,
+// so the epilogue does not wait on global memory).
+__device__ __forceinline__ void grad1_stage_r(double* __restrict__ rv, const double* __restrict__ yb, double mean,
+                                              int n, int I, int J, int tid) {
+  if (tid < 2 * NB) {
+    const int g = (tid < NB ? I : J) * NB + (tid < NB ? tid : tid - NB);
+    rv[tid] = g < n ? yb[g] - mean : 0.0;
+  }
+}
+
+__device__ __forceinline__ void grad1_partials(const v4d acc[NBT], bool diag, const double* __restrict__ rv,
+                                               double* __restrict__ lds, double* __restrict__ part, int wave,
+                                               int lane, int tid) {
   const int lr = lane & 15, lk = lane >> 4;
   double rI[4], rJ[NBT];
 #pragma unroll
-  for (int rr = 0; rr < 4; ++rr) {
-    const int gi = I * NB + 16 * wave + lk + 4 * rr;
-    rI[rr] = gi < n ? yb[gi] - mean : 0.0;
-  }
+  for (int rr = 0; rr < 4; ++rr) rI[rr] = rv[16 * wave + lk + 4 * rr];
 #pragma unroll
-  for (int t = 0; t < NBT; ++t) {
-    const int gj = J * NB + 16 * t + lr;
-    rJ[t] = gj < n ? yb[gj] - mean : 0.0;
-  }
+  for (int t = 0; t < NBT; ++t) rJ[t] = rv[NB + 16 * t + lr];
 #pragma unroll
   for (int rr = 0; rr < 4; ++rr) {
     double p = 0.0;
@@ -689,10 +693,12 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
   double* Ab = A + (size_t)b * N * N;
   const int lr = lane & 15, lk = lane >> 4;
   v4d acc[NBT];
+  __shared__ double rv[2 * NB];   // G1 only: r = y - c of the tile's row and column blocks
   if (t0 < ntri1) {
     int I, J; tri_decode(t0, I, J);
     if (I >= k) ++I;
     if (J >= k) ++J;
+    if (G1) grad1_stage_r(rv, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, J, tid);
     const double* Aop = Wo + (size_t)b * NB * N + I * NB;   // used negated
     const double* Bop = Wo + (size_t)b * NB * N + J * NB;
     double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + J * NB + lr;
@@ -711,8 +717,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
       }
       __syncthreads();   // chunk buffers are free: per-wave transposition scratch
       store_strip_transposed(acc, Ab + (size_t)(I * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr, wave);
-      if (G1) grad1_partials(acc, true, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, I, lds,
-                               part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
+      if (G1) grad1_partials(acc, true, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
     } else {
       tile_product_dma_latec(Aop, N, Bop, N, lds, acc, Ct, (size_t)N, wave, lane);
 #pragma unroll
@@ -721,12 +726,12 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
         for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
       if (G1) {
         __syncthreads();   // every wave is out of the chunk loop: the LDS buffers are free
-        grad1_partials(acc, false, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, J, lds,
-                       part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
+        grad1_partials(acc, false, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
       }
     }
   } else {
     int I = t0 - ntri1; if (I >= k) ++I;
+    if (G1) grad1_stage_r(rv, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, k, tid);
     const double* Aop = Wo + (size_t)b * NB * N + I * NB;
     const double* Bop = Mbuf + (size_t)b * NB * NB;
 #pragma unroll
@@ -744,8 +749,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
     }
     if (G1) {
       __syncthreads();
-      grad1_partials(acc, false, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, k, lds,
-                     part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
+      grad1_partials(acc, false, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
     }
   }
 }
