@@ -232,3 +232,30 @@ def test_fused_predict_pixels_entry_point_equals_staged_path(kid, s, chunk):
     o.current_scaling_factor = s
     want = o.predict_pixels(lr, lr, hi)
     assert np.abs(fused.cpu().numpy() - want).max() < 2e-3 / 255
+
+
+def test_non_default_options_vs_oracle():
+    """gprsr.py:17-26 options off their defaults, end to end: grid training points (n = 100 at p = 20: the
+    one-block N = 112 path of the fit), BILINEAR recombination, another stride and learning rate."""
+    from super_resolution_amd import gprsr, kernels as K, ops
+    from super_resolution_amd.gprsr import GPRSR, ColorSpace
+    from super_resolution_amd.image_patches import PatchInterpolationMode
+    from oracle import patches as opatch
+    lr = _lr_image(46, 52, 17)
+    saved = (gprsr.USE_ALL_PIXELS_FOR_TRAINING, gprsr.PATCH_INTERPOLATION, gprsr.STRIDE_PERCENTAGE, gprsr.LEARNING_RATE)
+    try:
+        gprsr.USE_ALL_PIXELS_FOR_TRAINING = False
+        gprsr.PATCH_INTERPOLATION = PatchInterpolationMode.BILINEAR
+        gprsr.STRIDE_PERCENTAGE = 0.7
+        gprsr.LEARNING_RATE = 0.05
+        g = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE)
+        got = g.apply_for_channel_device([ops.u8_to_unit(to_dev(lr))])[0].cpu().numpy()
+    finally:
+        (gprsr.USE_ALL_PIXELS_FOR_TRAINING, gprsr.PATCH_INTERPOLATION, gprsr.STRIDE_PERCENTAGE,
+         gprsr.LEARNING_RATE) = saved
+    o = osr.OracleGPRSR(2, ogp.MATERN32, "GRAYSCALE", chain=False, use_all_pixels=False, learning_rate=0.05,
+                        stride_percentage=0.7, patch_interpolation=opatch.BILINEAR)
+    want = o.apply_for_channel_float(lr)
+    assert got.shape == want.shape
+    assert np.abs(got - want).max() < 2e-3 / 255
+    assert all(int(f.sum()) == 0 for f in g.stats.flags)
