@@ -23,6 +23,16 @@ from . import ops
 from .image_patches import axis_starts
 
 
+class NotPSDError(RuntimeError):
+    """A patch covariance lost positive definiteness during the fit (a pivot <= 0 or NaN).
+
+    The reference fails the same way: GPyTorch's psd_safe_cholesky raises NotPSDError once its
+    jitter retries (1e-8, 1e-7, 1e-6 on float64) are exhausted.  With the
+    likelihood's noise floor of 1e-4 on the diagonal a finite patch cannot get there in
+    float64, and a jitter of <= 1e-6 cannot rescue one that does (NaN / Inf pixels), so the
+    retries are not replayed: the failure is reported per GP in `flags` and raised here."""
+
+
 class FitStats:
     """Per-call record (device tensors): raw hyper-parameters and failure flags."""
 

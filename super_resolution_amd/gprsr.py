@@ -70,6 +70,7 @@ class GPRSR:
         self.iters = iters
         self.shard = shard
         self.stats = engine.FitStats()
+        self.check_failures = True
         self._gp = engine.BatchedGP(kernel_id_of(used_kernel), iters=iters, lr=LEARNING_RATE,
                                     max_workspace_bytes=max_workspace_bytes)
 
@@ -106,12 +107,21 @@ class GPRSR:
         return res
 
     def apply_for_channel_device(self, imgs):
-        """Device float64 images in [0,1] -> device float64 HR images (before the uint8 cast)."""
+        """Device float64 images in [0,1] -> device float64 HR images (before the uint8 cast).
+        self.stats holds the raw hyper-parameters and failure flags of this call's predict_pixels passes;
+        a flagged GP raises engine.NotPSDError (the reference's failure mode) unless check_failures is False."""
+        self.stats = engine.FitStats()
         scaling_factor = self.scaling_factor
         while scaling_factor >= 4:
             scaling_factor /= 2
             imgs = self._do_algorithm(imgs, 2)
-        return self._do_algorithm(imgs, scaling_factor)
+        outs = self._do_algorithm(imgs, scaling_factor)
+        if self.check_failures:
+            bad = [int(f.sum()) for f in self.stats.flags]   # one device sync, at the end of the call
+            if any(bad):
+                raise engine.NotPSDError(f"{sum(bad)} patch GP(s) hit a non-positive pivot "
+                                         f"(per predict_pixels pass: {bad}); see GPRSR.stats.flags")
+        return outs
 
     def _do_algorithm(self, imgs, scaling_factor):
         self.current_scaling_factor = scaling_factor

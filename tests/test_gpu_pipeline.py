@@ -259,3 +259,20 @@ def test_non_default_options_vs_oracle():
     assert got.shape == want.shape
     assert np.abs(got - want).max() < 2e-3 / 255
     assert all(int(f.sum()) == 0 for f in g.stats.flags)
+
+
+def test_non_finite_patch_raises_like_the_reference():
+    """A GP whose factorisation breaks down is flagged per patch and raised as NotPSDError
+    (GPyTorch's failure mode after its jitter retries); the other patches are unaffected."""
+    from super_resolution_amd import engine, kernels as K, ops
+    from super_resolution_amd.gprsr import GPRSR, ColorSpace
+    lr = _lr_image(44, 40, 3).astype(np.float64) / 255.
+    lr[5, 7] = np.nan
+    g = GPRSR(2, K.rbf_kernel, ColorSpace.GRAYSCALE)
+    with pytest.raises(engine.NotPSDError):
+        g.apply_for_channel_device([to_dev(lr)])
+    flags = g.stats.flags[0].cpu().numpy()
+    assert flags.sum() >= 1 and flags.sum() < flags.size   # only the patches that contain the pixel
+    g.check_failures = False
+    out = g.apply_for_channel_device([to_dev(lr)])[0]
+    assert out.shape == (88, 80)
