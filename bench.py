@@ -18,7 +18,7 @@ and the predicted patches are all-gathered over RCCL; value = all output
 megapixels / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
-  roofline     : the dominant kernel (k_update, f64 MFMA tile products), HIP-event timed
+  roofline     : the dominant kernel (k_update2, f64 MFMA tile products), HIP-event timed
   cpu_baseline : the CPU oracle (torch f64 restatement of the GPyTorch loop) on a bounded sample
 """
 import argparse
@@ -98,8 +98,8 @@ def cpu_baseline(kernel_id, s, seconds_budget=20.0):
     return dt / done, done, cores
 
 
-def pmc_traffic(workload, B_local, N):
-    """HBM bytes per k_update launch from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
+def pmc_traffic(kernel, workload, B_local, N):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
     correction of MI355X_MICROARCH.md, + WRITE_SIZE), which were taken on 633 GPs of order 784 = this bench's
     default shape.  Counters cannot be read from inside this process: None for any other shape or if the
     summary is absent."""
@@ -108,7 +108,7 @@ def pmc_traffic(workload, B_local, N):
         return None
     try:
         with open(path) as f:
-            return round(json.load(f)["k_update_hbm_bytes_per_launch"]["traffic_corrected"])
+            return round(json.load(f)["hbm_bytes_per_launch"][kernel]["traffic_corrected"])
     except (KeyError, ValueError):
         return None
 
@@ -176,21 +176,28 @@ def main():
     ms_per_step = dt / a.steps * 1e3
     value = out_px / 1e6 / (dt / a.steps)
 
-    # roofline of the dominant kernel: k_update<false> = batched 112x112x112 f64 MFMA tile products (the last pivot
-    # step of each evaluation runs k_update<true>, same products + the alpha epilogue: listed as "update_last").
-    # Algorithmic flops of one launch (pivot step of B GPs): the symmetric trailing update
-    # (N-NB)^2*NB plus the triangular pivot-column product W*L^-1, (N-NB)*NB^2.
+    # roofline of the dominant kernel.  Pivots are taken two at a time: k_update2 applies both rank-112 updates of
+    # a pair in one pass over A (batched 112x112x224 f64 MFMA tile products).  Algorithmic flops of one launch, per
+    # GP, with R = N - 2*112 rows outside the pair: symmetric rank-224 update of the R x R trailing matrix R^2*224,
+    # pivot column of the first step + its update by the second 3*R*112^2, the first pivot block's symmetric update
+    # 112^3, the triangular pivot-column product of the second step (N-112)*112^2.  (Matrices of fewer than 3
+    # blocks have no pair: then k_update, (N-112)^2*112 + (N-112)*112^2.)
     n = (10 * s - 2) ** 2
     N = -(-n // NB) * NB
-    cnt, ms = prof["update"]
     B_local = -(-n_patches // world)
-    flops_launch = B_local * ((N - NB) ** 2 * NB + (N - NB) * NB * NB)
+    if prof.get("update2", (0, 0.0))[0]:
+        kname_dom, (cnt, ms) = "k_update2", prof["update2"]
+        R = N - 2 * NB
+        flops_launch = B_local * (R * R * 2 * NB + 3 * R * NB * NB + NB ** 3 + (N - NB) * NB * NB)
+    else:
+        kname_dom, (cnt, ms) = "k_update", prof["update"]
+        flops_launch = B_local * ((N - NB) ** 2 * NB + (N - NB) * NB * NB)
     avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
     achieved = flops_launch / avg_s / 1e12 if cnt else float("nan")
     kernel_ms = {k: round(v[1] / a.steps, 3) for k, v in prof.items()}
-    roofline = {"kernel": "k_update<false>", "bound": "mfma", "achieved": round(achieved, 3),
+    roofline = {"kernel": kname_dom, "bound": "mfma", "achieved": round(achieved, 3),
                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic(a.workload, B_local, N),
+                "traffic": pmc_traffic(kname_dom, a.workload, B_local, N),
                 "traffic_note": "HBM bytes per launch, profiles/r01_pmc_invert_633x784.json (separate rocprofv3 --pmc passes)",
                 "launches_per_step": cnt // max(1, a.steps), "avg_launch_ms": round(avg_s * 1e3, 4),
                 "flops_per_launch": flops_launch, "kernel_ms_per_step": kernel_ms}

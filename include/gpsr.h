@@ -221,6 +221,8 @@ enum {
   GPSR_PROF_UPDATE = 0, GPSR_PROF_PANEL, GPSR_PROF_PIVOT, GPSR_PROF_BUILD,
   GPSR_PROF_GRAD1, GPSR_PROF_GRAD2, GPSR_PROF_PREDICT,
   GPSR_PROF_UPDATE_LAST, /* k_update<true>: the last pivot step's launch, which also leaves the alpha partials */
+  GPSR_PROF_UPDATE2,     /* k_update2: both rank-112 updates of a two-pivot step in one pass over A */
+  GPSR_PROF_UPDATE_SEL,  /* k_update restricted to the next pivot's block row/column (first half of a two-pivot step) */
   GPSR_PROFILE_NTAGS
 };
 int gpsr_profile_begin(int max_records);

@@ -5,6 +5,7 @@
 
 #include <math.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 
 static thread_local char g_err[256] = "";
@@ -29,7 +30,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Optional HIP-event brackets around tagged launches, on the stream the kernel is
 // launched on.  Off by default; costs two hipEventRecord per tagged launch when on.
 #include <vector>
-enum { T_UPDATE = 0, T_PANEL, T_PIVOT, T_BUILD, T_GRAD1, T_GRAD2, T_PREDICT, T_UPDATE_LAST, T_NTAGS };
+enum { T_UPDATE = 0, T_PANEL, T_PIVOT, T_BUILD, T_GRAD1, T_GRAD2, T_PREDICT, T_UPDATE_LAST, T_UPDATE2, T_UPDATE_SEL, T_NTAGS };
 struct ProfRec { hipEvent_t a, b; int tag; };
 static std::vector<ProfRec> g_prof;
 static size_t g_prof_used = 0;
@@ -146,22 +147,45 @@ extern "C" int gpsr_covariance(const double* X, int B, int n, int d, int kernel_
 }
 
 // ---------------------------------------------------------------- inversion
-struct InvWs { double *Wo, *U, *M; };
+// Wo2 / U[1] / M[1]: second pivot of a two-pivot step (k_update2)
+struct InvWs { double *Wo, *Wo2, *U[2], *M[2]; };
 
 static size_t inv_ws_bytes(int B, int N) {
-  return align256((size_t)B * NB * N * 8) + 2 * align256((size_t)B * NB * NB * 8);
+  return 2 * align256((size_t)B * NB * N * 8) + 4 * align256((size_t)B * NB * NB * 8);
 }
 static InvWs inv_ws_carve(char* base, int B, int N) {
   InvWs w;
   w.Wo = (double*)base; base += align256((size_t)B * NB * N * 8);
-  w.U = (double*)base; base += align256((size_t)B * NB * NB * 8);
-  w.M = (double*)base;
+  w.Wo2 = (double*)base; base += align256((size_t)B * NB * N * 8);
+  for (int i = 0; i < 2; ++i) {
+    w.U[i] = (double*)base; base += align256((size_t)B * NB * NB * 8);
+    w.M[i] = (double*)base; base += align256((size_t)B * NB * NB * 8);
+  }
   return w;
 }
 
-// sweeps every pivot block of B matrices; logdet must have been zeroed
+static const bool g_pair_steps = getenv("GPSR_SINGLE_STEPS") == nullptr;   // debugging switch: one pivot per pass
+
+static int launch_pivot(double* A, int B, int N, int k, double* U, double* M, double* logdet, int32_t* flags,
+                        hipStream_t st) {
+  ProfRec* pr = prof_start(T_PIVOT, st);
+  hipLaunchKernelGGL(k_pivot, dim3(B), dim3(MM_THREADS), PIVOT_LDS_BYTES, st, A, N, k, U, M, logdet, flags);
+  prof_stop(pr, st);
+  CHECK_LAUNCH("k_pivot");
+  return 0;
+}
+static int launch_panel(const double* A, int B, int N, int k, const double* U, double* Wo, hipStream_t st) {
+  const int nblk = N / NB, tp = (nblk - 1) * B;
+  ProfRec* pr = prof_start(T_PANEL, st);
+  hipLaunchKernelGGL(k_panel, dim3(tp), dim3(MM_THREADS), 0, st, A, N, nblk, k, U, Wo, tp);
+  prof_stop(pr, st);
+  CHECK_LAUNCH("k_panel");
+  return 0;
+}
+
 // y / raw / part non-null: the last update launch also leaves the mat-vec partials of
 // alpha = K^-1 (y - c) (grad1_partials), n = number of real rows.
+// sweeps every pivot block of B matrices; logdet must have been zeroed
 static int launch_sweeps(double* A, int B, int N, const InvWs& w, double* logdet, int32_t* flags, hipStream_t st,
                          const double* y = nullptr, const float* raw = nullptr, int n = 0, double* part = nullptr) {
   const int nblk = N / NB;
@@ -172,26 +196,47 @@ static int launch_sweeps(double* A, int B, int N, const InvWs& w, double* logdet
     if (e != hipSuccess) return hip_fail(e, "pivot lds attr");
     lds_attr_set = true;
   }
-  for (int k = 0; k < nblk; ++k) {
-    ProfRec* pr = prof_start(T_PIVOT, st);
-    hipLaunchKernelGGL(k_pivot, dim3(B), dim3(MM_THREADS), PIVOT_LDS_BYTES, st, A, N, k, w.U, w.M, logdet, flags);
-    prof_stop(pr, st);
-    CHECK_LAUNCH("k_pivot");
-    if (nblk > 1) {
-      const int tp = (nblk - 1) * B;
-      pr = prof_start(T_PANEL, st);
-      hipLaunchKernelGGL(k_panel, dim3(tp), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.U, w.Wo, tp);
+  const int ntri1 = (nblk - 1) * nblk / 2;
+  // pivots are taken two at a time while at least one single step remains for the end (the alpha epilogue
+  // lives in the single-step kernel): nblk odd -> (nblk-1)/2 pairs + 1 single, even -> (nblk-2)/2 pairs + 2
+  const int npairs = (g_pair_steps && nblk >= 3) ? (nblk - 1 - (nblk % 2 == 0 ? 1 : 0)) / 2 : 0;
+  int rc;
+  int k = 0;
+  for (int m = 0; m < npairs; ++m, k += 2) {
+    const int k1 = k, k2 = k + 1;
+    if ((rc = launch_pivot(A, B, N, k1, w.U[0], w.M[0], logdet, flags, st))) return rc;
+    if ((rc = launch_panel(A, B, N, k1, w.U[0], w.Wo, st))) return rc;
+    {
+      const int tu = nblk * B;   // the tiles of block row / column k2 only
+      ProfRec* pr = prof_start(T_UPDATE_SEL, st);
+      hipLaunchKernelGGL(k_update<false>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k1, w.Wo, w.M[0], ntri1, tu,
+                         (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, k2);
       prof_stop(pr, st);
-      CHECK_LAUNCH("k_panel");
-      const int ntri1 = (nblk - 1) * nblk / 2, tu = (ntri1 + nblk - 1) * B;
+      CHECK_LAUNCH("k_update(sel)");
+    }
+    if ((rc = launch_pivot(A, B, N, k2, w.U[1], w.M[1], logdet, flags, st))) return rc;
+    if ((rc = launch_panel(A, B, N, k2, w.U[1], w.Wo2, st))) return rc;
+    {
+      const int nb2 = nblk - 2, per = nb2 * (nb2 + 1) / 2 + nb2 + 1 + nblk - 1, tu = per * B;
+      ProfRec* pr = prof_start(T_UPDATE2, st);
+      hipLaunchKernelGGL(k_update2, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k1, w.Wo, w.Wo2, w.M[0], w.M[1], tu);
+      prof_stop(pr, st);
+      CHECK_LAUNCH("k_update2");
+    }
+  }
+  for (; k < nblk; ++k) {
+    if ((rc = launch_pivot(A, B, N, k, w.U[0], w.M[0], logdet, flags, st))) return rc;
+    if (nblk > 1) {
+      if ((rc = launch_panel(A, B, N, k, w.U[0], w.Wo, st))) return rc;
+      const int tu = (ntri1 + nblk - 1) * B;
       const bool last = (k == nblk - 1) && part;
-      pr = prof_start(last ? T_UPDATE_LAST : T_UPDATE, st);
+      ProfRec* pr = prof_start(last ? T_UPDATE_LAST : T_UPDATE, st);
       if (last)
-        hipLaunchKernelGGL(k_update<true>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M, ntri1, tu,
-                           y, raw, n, part);
+        hipLaunchKernelGGL(k_update<true>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M[0], ntri1, tu,
+                           y, raw, n, part, -1);
       else
-        hipLaunchKernelGGL(k_update<false>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M, ntri1, tu,
-                           (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr);
+        hipLaunchKernelGGL(k_update<false>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M[0], ntri1, tu,
+                           (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, -1);
       prof_stop(pr, st);
       CHECK_LAUNCH("k_update");
     }

@@ -679,25 +679,79 @@ __device__ __forceinline__ void grad1_partials(const v4d acc[NBT], bool diag, co
   }
 }
 
+// Two-phase product for the fused update of TWO pivot steps: acc += (+-)A1 B1 + (+-)A2 B2 with one
+// pass over C (k-depth 224), the 14 chunks double-buffered as one continuous stream.  LATEC as in
+// tile_product_dma_latec (C read overlapped with chunk 0, which runs on zeroed accumulators).
+template <int SKIP1, bool NEG1, int SKIP2, bool NEG2, bool LATEC>
+__device__ __forceinline__ void tile_product_dma2(const double* __restrict__ A1, int lda1, const double* __restrict__ B1,
+                                                  int ldb1, const double* __restrict__ A2, int lda2,
+                                                  const double* __restrict__ B2, int ldb2, double* __restrict__ lds,
+                                                  v4d acc[NBT], const double* __restrict__ Ct, size_t ldc, int wave,
+                                                  int lane) {
+  constexpr int NC = NB / KC;
+  dma_chunk(A1, lda1, B1, ldb1, 0, lds, lds + DMA_CHUNK, wave, lane);
+  v4d c0[NBT];
+  if (LATEC) {
+#pragma unroll
+    for (int t = 0; t < NBT; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) c0[t][rr] = Ct[(size_t)(4 * rr) * ldc + 16 * t];
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+#pragma unroll
+  for (int g = 0; g < 2 * NC; ++g) {
+    double* cur = lds + (g & 1) * 2 * DMA_CHUNK;
+    double* nxt = lds + ((g + 1) & 1) * 2 * DMA_CHUNK;
+    if (LATEC && g == 0) {
+      asm volatile("s_waitcnt vmcnt(28)" ::: "memory");   // chunk 0's DMA pieces are older than the 28 C loads
+      __builtin_amdgcn_s_barrier();
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+    if (g + 1 < NC) dma_chunk(A1, lda1, B1, ldb1, g + 1, nxt, nxt + DMA_CHUNK, wave, lane);
+    else if (g + 1 < 2 * NC) dma_chunk(A2, lda2, B2, ldb2, g + 1 - NC, nxt, nxt + DMA_CHUNK, wave, lane);
+    if (g < NC) chunk_mfma_dma<SKIP1, NEG1>(cur, cur + DMA_CHUNK, acc, wave, lane, g);
+    else chunk_mfma_dma<SKIP2, NEG2>(cur, cur + DMA_CHUNK, acc, wave, lane, g - NC);
+    if (LATEC && g == 0) {
+#pragma unroll
+      for (int t = 0; t < NBT; ++t) acc[t] += c0[t];
+    }
+  }
+}
+
 template <bool G1>   // G1: last pivot step of a fit evaluation, leaves the alpha mat-vec partials (own instantiation:
                      // the epilogue's registers must not weigh on the six launches that do not need it)
 __global__ void __launch_bounds__(MM_THREADS, 4)
 k_update(double* __restrict__ A, int N, int nblk, int k,
              const double* __restrict__ Wo, const double* __restrict__ Mbuf, int ntri1, int total,
-             const double* __restrict__ y, const float* __restrict__ raw, int n, double* __restrict__ part) {
+             const double* __restrict__ y, const float* __restrict__ raw, int n, double* __restrict__ part,
+             int sel) {
   __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int v = xcd_remap(blockIdx.x, total);
-  const int per = ntri1 + nblk - 1;
+  // sel < 0: every tile of the step.  sel >= 0 (first half of a two-pivot step): only the nblk tiles that
+  // the NEXT pivot's panel reads, i.e. those of block row / column `sel`: the nblk-1 trailing tiles
+  // (sel, other) / (other, sel) and the pivot-column tile of row block sel.
+  const int per = sel < 0 ? ntri1 + nblk - 1 : nblk;
   const int b = v / per, t0 = v % per;
   double* Ab = A + (size_t)b * N * N;
   const int lr = lane & 15, lk = lane >> 4;
   v4d acc[NBT];
   __shared__ double rv[2 * NB];   // G1 only: r = y - c of the tile's row and column blocks
-  if (t0 < ntri1) {
-    int I, J; tri_decode(t0, I, J);
-    if (I >= k) ++I;
-    if (J >= k) ++J;
+  int I, J;
+  bool trailing;
+  if (sel < 0) {
+    trailing = t0 < ntri1;
+    if (trailing) { tri_decode(t0, I, J); if (I >= k) ++I; if (J >= k) ++J; }
+    else { I = t0 - ntri1; if (I >= k) ++I; J = k; }
+  } else {
+    trailing = t0 < nblk - 1;
+    if (trailing) { const int other = t0 + (t0 >= k ? 1 : 0); I = other > sel ? other : sel; J = other > sel ? sel : other; }
+    else { I = sel; J = k; }
+  }
+  if (trailing) {
     if (G1) grad1_stage_r(rv, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, J, tid);
     const double* Aop = Wo + (size_t)b * NB * N + I * NB;   // used negated
     const double* Bop = Wo + (size_t)b * NB * N + J * NB;
@@ -730,7 +784,6 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
       }
     }
   } else {
-    int I = t0 - ntri1; if (I >= k) ++I;
     if (G1) grad1_stage_r(rv, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, k, tid);
     const double* Aop = Wo + (size_t)b * NB * N + I * NB;
     const double* Bop = Mbuf + (size_t)b * NB * NB;
@@ -750,6 +803,108 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
     if (G1) {
       __syncthreads();
       grad1_partials(acc, false, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
+    }
+  }
+}
+
+// ------------------------------------------------- update of two pivot steps at once
+// After pivot k1, panel k1 (-> Wo1), the nblk tiles of block row/column k2 = k1+1 (k_update with
+// sel = k2), pivot k2 and panel k2 (-> Wo2), every other tile takes both rank-112 updates in ONE
+// pass over A (k-depth 224: C is read and written once instead of twice):
+//   (a) trailing (I,J), I,J not in {k1,k2}:  A_IJ  -= W1_I W1_J^T + W2_I W2_J^T
+//   (b) I not in {k1,k2}:                    A_Ik1  = W1_I M1 - W2_I W2_k1^T   (pivot column of step k1, then trailing of k2)
+//   (c) tile (k1,k1) (= -P1 from pivot k1):  A_k1k1 -= W2_k1 W2_k1^T
+//   (d) I != k2:                             A_Ik2  = W2_I M2                  (pivot column of step k2)
+// grid.x = (ntri(nblk-2) + (nblk-2) + 1 + (nblk-1)) * B.
+__global__ void __launch_bounds__(MM_THREADS, 4)
+k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restrict__ Wo1,
+          const double* __restrict__ Wo2, const double* __restrict__ M1buf, const double* __restrict__ M2buf,
+          int total) {
+  __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  const int v = xcd_remap(blockIdx.x, total);
+  const int k2 = k1 + 1, nb2 = nblk - 2, ntri2 = nb2 * (nb2 + 1) / 2;
+  const int per = ntri2 + nb2 + 1 + nblk - 1;
+  const int b = v / per, t0 = v % per;
+  double* Ab = A + (size_t)b * N * N;
+  const double* W1 = Wo1 + (size_t)b * NB * N;
+  const double* W2 = Wo2 + (size_t)b * NB * N;
+  v4d acc[NBT];
+  if (t0 < ntri2) {                                   // (a)
+    int I, J; tri_decode(t0, I, J);
+    if (I >= k1) I += 2;
+    if (J >= k1) J += 2;
+    double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + J * NB + lr;
+    if (I == J) {
+#pragma unroll
+      for (int t = 0; t < NBT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * N + 16 * t] : 0.0;
+      tile_product_dma2<SKIP_DIAG, true, SKIP_DIAG, true, false>(W1 + I * NB, N, W1 + J * NB, N, W2 + I * NB, N,
+                                                                 W2 + J * NB, N, lds, acc, Ct, (size_t)N, wave, lane);
+#pragma unroll
+      for (int t = 0; t < NBT; ++t) {
+        if (t > wave) break;
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+      }
+      __syncthreads();
+      store_strip_transposed(acc, Ab + (size_t)(I * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr, wave);
+    } else {
+      tile_product_dma2<SKIP_NONE, true, SKIP_NONE, true, true>(W1 + I * NB, N, W1 + J * NB, N, W2 + I * NB, N,
+                                                                W2 + J * NB, N, lds, acc, Ct, (size_t)N, wave, lane);
+#pragma unroll
+      for (int t = 0; t < NBT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+    }
+  } else if (t0 < ntri2 + nb2) {                      // (b)
+    int I = t0 - ntri2; if (I >= k1) I += 2;
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    tile_product_dma2<SKIP_LOWER, false, SKIP_NONE, true, false>(W1 + I * NB, N, M1buf + (size_t)b * NB * NB, NB,
+                                                                 W2 + I * NB, N, W2 + k1 * NB, N, lds, acc, nullptr,
+                                                                 0, wave, lane);
+    if (I > k1) {
+      double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + k1 * NB + lr;
+#pragma unroll
+      for (int t = 0; t < NBT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+    } else {
+      __syncthreads();
+      store_strip_transposed(acc, Ab + (size_t)(k1 * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr);
+    }
+  } else if (t0 == ntri2 + nb2) {                     // (c)
+    double* Ct = Ab + (size_t)(k1 * NB + 16 * wave + lk) * N + k1 * NB + lr;
+#pragma unroll
+    for (int t = 0; t < NBT; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * N + 16 * t] : 0.0;
+    tile_product_dma<SKIP_DIAG, true>(W2 + k1 * NB, N, W2 + k1 * NB, N, lds, acc, wave, lane);
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) {
+      if (t > wave) break;
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+    }
+    __syncthreads();
+    store_strip_transposed(acc, Ab + (size_t)(k1 * NB) * N + k1 * NB, (size_t)N, lds, wave, lane, 1.0, nullptr, wave);
+  } else {                                            // (d)
+    int I = t0 - (ntri2 + nb2 + 1); if (I >= k2) ++I;
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    tile_product_dma<SKIP_LOWER, false>(W2 + I * NB, N, M2buf + (size_t)b * NB * NB, NB, lds, acc, wave, lane);
+    if (I > k2) {
+      double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + k2 * NB + lr;
+#pragma unroll
+      for (int t = 0; t < NBT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+    } else {
+      __syncthreads();
+      store_strip_transposed(acc, Ab + (size_t)(k2 * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr);
     }
   }
 }

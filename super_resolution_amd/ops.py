@@ -249,7 +249,7 @@ def axpy(a, b, alpha):
 
 
 # ------------------------------------------------------------ kernel timing
-PROF_TAGS = ("update", "panel", "pivot", "build", "grad1", "grad2", "predict", "update_last")
+PROF_TAGS = ("update", "panel", "pivot", "build", "grad1", "grad2", "predict", "update_last", "update2", "update_sel")
 
 
 def profile_begin(max_records=65536):

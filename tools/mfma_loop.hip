@@ -6,6 +6,7 @@
 typedef double v4d __attribute__((ext_vector_type(4)));
 #define NB 112
 #define KC 16
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <int WAVES, bool BARRIER, int NACC>
 __global__ void __launch_bounds__(64 * WAVES, 4) k_loop(double* out, int chunks) {
@@ -38,7 +39,6 @@ __global__ void __launch_bounds__(64 * WAVES, 4) k_loop(double* out, int chunks)
   if (s == 12345.678) out[0] = s;
 }
 
-#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
 template <int WAVES, bool BARRIER, int NACC>
 int run(double* out, const char* name) {
@@ -56,6 +56,63 @@ int run(double* out, const char* name) {
   return 0;
 }
 
+
+// 14 waves per workgroup: each 16-row strip split into two waves (column blocks 0-3 and 4-6)
+template <bool BARRIER>
+__global__ void __launch_bounds__(896, 7) k_loop14(double* out, int chunks) {
+  __shared__ double lds[4 * KC * NB];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int e = tid; e < 4 * KC * NB; e += 896) lds[e] = 1e-3 * (e % 97);
+  __syncthreads();
+  const int strip = wave % 7, half = wave / 7;
+  v4d acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int ch = 0; ch < chunks; ++ch) {
+    const double* As = lds + (ch & 1) * 2 * KC * NB;
+    const double* Bs = As + KC * NB;
+    if (BARRIER) __syncthreads();
+    if (half == 0) {
+#pragma unroll
+      for (int ks = 0; ks < KC / 4; ++ks) {
+        const int row = (ks * 4 + lk) * NB;
+        const double av = As[row + 16 * strip + lr];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[row + 16 * t + lr], acc[t], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KC / 4; ++ks) {
+        const int row = (ks * 4 + lk) * NB;
+        const double av = As[row + 16 * strip + lr];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[row + 16 * (4 + t) + lr], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+  if (s == 12345.678) out[0] = s;
+}
+
+template <bool BARRIER>
+int run14(double* out, const char* name) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int chunks = 700, grid = 256 * 2 * 8;
+  hipLaunchKernelGGL((k_loop14<BARRIER>), dim3(grid), dim3(896), 0, 0, out, 7);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL((k_loop14<BARRIER>), dim3(grid), dim3(896), 0, 0, out, chunks);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)grid * 49 * chunks * 4 * 2048.0;
+  printf("%-34s %.3f ms  %.1f TFLOP/s\n", name, ms, flops / ms * 1e-9);
+  return 0;
+}
+
 int main() {
   double* out; CK(hipMalloc(&out, 8));
   run<7, true, 7>(out, "7 waves, barrier/chunk, 7 acc");
@@ -64,5 +121,7 @@ int main() {
   run<4, false, 7>(out, "4 waves, no barrier, 7 acc");
   run<8, true, 7>(out, "8 waves, barrier/chunk, 7 acc");
   run<8, false, 7>(out, "8 waves, no barrier, 7 acc");
+  run14<true>(out, "14 half-strip waves, barrier");
+  run14<false>(out, "14 half-strip waves, no barrier");
   return 0;
 }

@@ -4,7 +4,7 @@ usage: python tools/pmc_summarize.py <pmc_out_dir> <out.json>
 
 For every *_counter_collection.csv below <pmc_out_dir>: per library kernel (k_*) and
 counter, the number of dispatches and the mean counter value per dispatch.  Adds the
-derived HBM figures for k_update with the gfx950 correction of MI355X_MICROARCH.md
+derived HBM figures per kernel with the gfx950 correction of MI355X_MICROARCH.md
 (FETCH_SIZE counts 128-B requests of 16 B/lane reads at 64 B: doubled for the LDS-DMA
 operand reads; WRITE_SIZE is exact).  rocprofv3 reports both in KiB.
 """
@@ -39,13 +39,14 @@ def main(src, dst):
            "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; other counters raw",
            "kernels": {k: {c: {"launches": v[0], "mean_per_launch": v[1] / v[0]} for c, v in sorted(cs.items())}
                        for k, cs in sorted(acc.items())}}
-    upd = out["kernels"].get("k_update", {})
-    if "FETCH_SIZE" in upd and "WRITE_SIZE" in upd:
-        f, w = upd["FETCH_SIZE"]["mean_per_launch"] * 1024, upd["WRITE_SIZE"]["mean_per_launch"] * 1024
-        out["k_update_hbm_bytes_per_launch"] = {
-            "fetch_raw": f, "fetch_corrected_x2": 2 * f, "write": w, "traffic_corrected": 2 * f + w,
-            "note": "x2 is the guide's gfx950 correction for 16 B/lane reads (the LDS-DMA operand chunks); the C-tile "
-                    "reads are 8 B/lane and uncalibrated, so the corrected figure is an upper bound"}
+    out["hbm_bytes_per_launch"] = {}
+    for kname, cs in out["kernels"].items():
+        if "FETCH_SIZE" in cs and "WRITE_SIZE" in cs:
+            f, w = cs["FETCH_SIZE"]["mean_per_launch"] * 1024, cs["WRITE_SIZE"]["mean_per_launch"] * 1024
+            out["hbm_bytes_per_launch"][kname] = {"fetch_raw": f, "fetch_corrected_x2": 2 * f, "write": w,
+                                                  "traffic_corrected": 2 * f + w}
+    out["hbm_note"] = ("x2 is the guide's gfx950 correction for 16 B/lane reads (the LDS-DMA operand chunks); the C-tile "
+                       "reads are 8 B/lane and uncalibrated, so the corrected figure is an upper bound")
     with open(dst, "w") as f:
         json.dump(out, f, indent=1)
     print("wrote", dst, "kernels:", ", ".join(out["kernels"]))
