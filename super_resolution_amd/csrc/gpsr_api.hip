@@ -116,12 +116,12 @@ extern "C" int gpsr_init_hypers(const double* y, int B, int n, int kernel_id, fl
 static size_t build_lds(int d) { return (size_t)2 * NB * (d + 1) * sizeof(double); }
 
 static int launch_build(const double* X, int B, int n, int N, int d, int kid, const float* raw, double* A,
-                        double* logdet, hipStream_t st) {
+                        double* logdet, hipStream_t st, int full_diag) {
   const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2, total = ntri * B;
   const size_t lds = build_lds(d);
 #define BUILD(K)                                                                                              \
   do {                                                                                                        \
-    if (d == 8) hipLaunchKernelGGL((k_build8<K>), dim3(total), dim3(MM_THREADS), 0, st, X, raw, A, n, N, ntri, total, logdet); \
+    if (d == 8) hipLaunchKernelGGL((k_build8<K>), dim3(total), dim3(MM_THREADS), 0, st, X, raw, A, n, N, ntri, total, logdet, full_diag); \
     else hipLaunchKernelGGL((k_build<K>), dim3(total), dim3(256), lds, st, X, raw, A, n, N, d, ntri, total, logdet);           \
   } while (0)
   ProfRec* pr = prof_start(T_BUILD, st);
@@ -143,7 +143,7 @@ extern "C" int gpsr_covariance(const double* X, int B, int n, int d, int kernel_
   if (B <= 0) return 0;
   if (!X || !raw || !K) return arg_fail("null pointer");
   if (n < 1 || d < 1 || d > 64 || kernel_id < 0 || kernel_id > 4) return arg_fail("covariance shape");
-  return launch_build(X, B, n, gpsr_padded_n(n), d, kernel_id, raw, K, nullptr, (hipStream_t)stream);
+  return launch_build(X, B, n, gpsr_padded_n(n), d, kernel_id, raw, K, nullptr, (hipStream_t)stream, 1);
 }
 
 // ---------------------------------------------------------------- inversion
@@ -325,7 +325,7 @@ static int launch_grad2(const FitWs& w, const double* X, const float* raw, const
 // K build + inversion + alpha (+ gradient statistics when with_grad)
 static int eval_once(const FitWs& w, const double* X, const double* y, const float* raw, double* alpha,
                      int32_t* flags, int B, int n, int N, int d, int kid, bool with_grad, hipStream_t st) {
-  int rc = launch_build(X, B, n, N, d, kid, raw, w.A, w.logdet, st);
+  int rc = launch_build(X, B, n, N, d, kid, raw, w.A, w.logdet, st, 0);   // diagonal tiles: lower sub-blocks only
   if (rc) return rc;
   const int nblk = N / NB;
   const bool fused = nblk > 1;   // alpha's mat-vec rides on the last update launch; one block: nothing to ride on

@@ -212,12 +212,22 @@ __global__ void k_build(const double* __restrict__ X, const float* __restrict__ 
 template <int KID>
 __global__ void __launch_bounds__(MM_THREADS)
 k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __restrict__ A, int n, int N,
-         int ntri, int total, double* __restrict__ logdet) {
+         int ntri, int total, double* __restrict__ logdet, int full_diag) {
   __shared__ __attribute__((aligned(16))) double xi[NB * 8];
   const int v = xcd_remap(blockIdx.x, total);
   const int b = v / ntri, t = v % ntri;
   int I, J; tri_decode(t, I, J);
-  const int tid = threadIdx.x, g = tid / NB, j = tid - g * NB;
+  const int tid = threadIdx.x;
+  // Diagonal tiles inside the fit: the sweep reads only the 16x16 sub-blocks on and below the diagonal
+  // (k_pivot, the SKIP_DIAG updates), so only those 28 of 49 are evaluated: 16 threads per sub-block, one
+  // column each.  gpsr_covariance (full_diag) keeps whole diagonal tiles.
+  const bool sub = (I == J) && !full_diag;
+  int g, j, i0 = 0, istep = 4, iend = NB;
+  if (!sub) { g = tid / NB; j = tid - g * NB; i0 = g; }
+  else {
+    int bi, bj; tri_decode(tid >> 4, bi, bj);
+    j = 16 * bj + (tid & 15); i0 = 16 * bi; istep = 1; iend = i0 + 16; g = 0;
+  }
   const double* Xb = X + (size_t)b * n * 8;
   const int gj = J * NB + j;
   double xj[8];
@@ -232,7 +242,7 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
   __syncthreads();
   double* Ab = A + (size_t)b * N * N + (size_t)(I * NB) * N + gj;
 #pragma unroll 2
-  for (int i = g; i < NB; i += 4) {
+  for (int i = i0; i < iend; i += istep) {
     const int gi = I * NB + i;
     double val;
     if (gi < n && gj < n) {
@@ -1170,7 +1180,18 @@ k_grad2_8(const double* __restrict__ A, const double* __restrict__ X, const floa
   const int v = xcd_remap(blockIdx.x, total);
   const int b = v / ntri, t = v % ntri;
   int I, J; tri_decode(t, I, J);
-  const int tid = threadIdx.x, g = tid / NB, j = tid - g * NB;
+  const int tid = threadIdx.x;
+  // diagonal tiles: only the 28 sub-blocks on and below the diagonal (16 threads each, one column per
+  // thread); the strictly-lower ones count twice (symmetry), as the off-diagonal tiles do
+  const bool sub = (I == J);
+  int j, i0, istep = 4, iend = NB;
+  double wsym = 1.0;
+  if (!sub) { const int g = tid / NB; j = tid - g * NB; i0 = g; }
+  else {
+    int bi, bj; tri_decode(tid >> 4, bi, bj);
+    j = 16 * bj + (tid & 15); i0 = 16 * bi; istep = 1; iend = i0 + 16;
+    if (bi != bj) wsym = 2.0;
+  }
   const double* Xb = X + (size_t)b * n * 8;
   const int gj = J * NB + j;
   double xj[8];
@@ -1188,9 +1209,9 @@ k_grad2_8(const double* __restrict__ A, const double* __restrict__ X, const floa
   double s0 = 0.0, s1 = 0.0;
   if (gj < n) {
 #pragma unroll 2
-    for (int i = g; i < NB; i += 4) {
+    for (int i = i0; i < iend; i += istep) {
       if (I * NB + i < n) {
-        const double w = -Ab[(size_t)i * N] - ai[i] * aj;
+        const double w = wsym * (-Ab[(size_t)i * N] - ai[i] * aj);
         const double st = pair_stat<KID>(xi + i * 8, xj, 8);
         double kv, dk;
         kern_val_dl<KID>(st, h, kv, dk);
