@@ -122,6 +122,9 @@ def main():
     ap.add_argument("--kernel", default="matern52")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--max-workspace-gb", type=float, default=48.0)
+    ap.add_argument("--dual-stream", action="store_true",
+                    help="gpsr_set_dual_stream(1): two half-batches on two streams (+5 %% throughput; per-launch "
+                         "durations then overlap, so the roofline object describes launches that share the GPU)")
     a = ap.parse_args()
 
     from super_resolution_amd import dist as gdist
@@ -137,6 +140,7 @@ def main():
             "exponential": K.exponential_kernel}[a.kernel]
     if a.workload == "4kx2" and a.kernel == "matern52":
         kern = K.matern32_kernel  # BASELINE.json config 4
+    ops.set_dual_stream(a.dual_stream)
     imgs_u8, s = workload(a.workload, world)
     out_px = sum(im.shape[0] * s * im.shape[1] * s for im in imgs_u8)
     n_patches = sum(patch_count(im.shape, s) for im in imgs_u8)
@@ -189,6 +193,8 @@ def main():
         kname_dom, (cnt, ms) = "k_update2", prof["update2"]
         R = N - 2 * NB
         flops_launch = B_local * (R * R * 2 * NB + 3 * R * NB * NB + NB ** 3 + (N - NB) * NB * NB)
+        if a.dual_stream:
+            flops_launch //= 2   # each launch covers a half-batch
     else:
         kname_dom, (cnt, ms) = "k_update", prof["update"]
         flops_launch = B_local * ((N - NB) ** 2 * NB + (N - NB) * NB * NB)
@@ -221,7 +227,7 @@ def main():
             "config": {"workload": f"{a.workload}: {len(imgs_u8)} images, {n_patches} patches, "
                                    f"{2 * n_patches} GP fits (n={n}), {out_px / 1e6:.4f} output Mpx",
                        "kernel": kname,
-                       "color": "GRAYSCALE", "warm_start": "independent",
+                       "color": "GRAYSCALE", "warm_start": "independent", "dual_stream": bool(a.dual_stream),
                        "parallelism": f"patch-sharded x{world}"},
             "nonpositive_pivot_flags": flags_bad,
             "roofline": roofline, "cpu_baseline": cpu}

@@ -116,6 +116,15 @@ int gpsr_fit(const double* X, const double* y, int B, int n, int d, int kernel_i
              void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * Opt-in: gpsr_fit runs a batch of >= 256 GPs as two half-batches on two streams (the caller's and an
+ * internal one, forked from and joined to it with events), which fills part of the machine that the small
+ * latency-bound launches of one batch leave idle (+5 % throughput on Set14 x3).  Results are bit-identical.
+ * Off by default: overlapping launches make per-launch timings (gpsr_profile_*) ambiguous.  Process-wide,
+ * returns the previous setting.  No counterpart in the reference.
+ */
+int gpsr_set_dual_stream(int on);
+
+/*
  * One evaluation of the loss and of d loss / d raw (no Adam step), for tests:
  * what loss.backward() leaves in .grad at gprsr.py:185.   grad : [B][4] float32
  */

@@ -30,6 +30,7 @@ SIGNATURES = {
     "gpsr_fit_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gpsr_fit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gpsr_set_dual_stream": (c_int, [c_int]),
     "gpsr_loss_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "gpsr_predict": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p]),

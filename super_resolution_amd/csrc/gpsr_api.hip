@@ -183,88 +183,7 @@ static int launch_panel(const double* A, int B, int N, int k, const double* U, d
   return 0;
 }
 
-// y / raw / part non-null: the last update launch also leaves the mat-vec partials of
-// alpha = K^-1 (y - c) (grad1_partials), n = number of real rows.
-// sweeps every pivot block of B matrices; logdet must have been zeroed
-static int launch_sweeps(double* A, int B, int N, const InvWs& w, double* logdet, int32_t* flags, hipStream_t st,
-                         const double* y = nullptr, const float* raw = nullptr, int n = 0, double* part = nullptr) {
-  const int nblk = N / NB;
-  static bool lds_attr_set = false;
-  if (!lds_attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_pivot, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)PIVOT_LDS_BYTES);
-    if (e != hipSuccess) return hip_fail(e, "pivot lds attr");
-    lds_attr_set = true;
-  }
-  const int ntri1 = (nblk - 1) * nblk / 2;
-  // pivots are taken two at a time while at least one single step remains for the end (the alpha epilogue
-  // lives in the single-step kernel): nblk odd -> (nblk-1)/2 pairs + 1 single, even -> (nblk-2)/2 pairs + 2
-  const int npairs = (g_pair_steps && nblk >= 3) ? (nblk - 1 - (nblk % 2 == 0 ? 1 : 0)) / 2 : 0;
-  int rc;
-  int k = 0;
-  for (int m = 0; m < npairs; ++m, k += 2) {
-    const int k1 = k, k2 = k + 1;
-    if ((rc = launch_pivot(A, B, N, k1, w.U[0], w.M[0], logdet, flags, st))) return rc;
-    if ((rc = launch_panel(A, B, N, k1, w.U[0], w.Wo, st))) return rc;
-    {
-      const int tu = nblk * B;   // the tiles of block row / column k2 only
-      ProfRec* pr = prof_start(T_UPDATE_SEL, st);
-      hipLaunchKernelGGL(k_update<false>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k1, w.Wo, w.M[0], ntri1, tu,
-                         (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, k2);
-      prof_stop(pr, st);
-      CHECK_LAUNCH("k_update(sel)");
-    }
-    if ((rc = launch_pivot(A, B, N, k2, w.U[1], w.M[1], logdet, flags, st))) return rc;
-    if ((rc = launch_panel(A, B, N, k2, w.U[1], w.Wo2, st))) return rc;
-    {
-      const int nb2 = nblk - 2, per = nb2 * (nb2 + 1) / 2 + nb2 + 1 + nblk - 1, tu = per * B;
-      ProfRec* pr = prof_start(T_UPDATE2, st);
-      hipLaunchKernelGGL(k_update2, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k1, w.Wo, w.Wo2, w.M[0], w.M[1], tu);
-      prof_stop(pr, st);
-      CHECK_LAUNCH("k_update2");
-    }
-  }
-  for (; k < nblk; ++k) {
-    if ((rc = launch_pivot(A, B, N, k, w.U[0], w.M[0], logdet, flags, st))) return rc;
-    if (nblk > 1) {
-      if ((rc = launch_panel(A, B, N, k, w.U[0], w.Wo, st))) return rc;
-      const int tu = (ntri1 + nblk - 1) * B;
-      const bool last = (k == nblk - 1) && part;
-      ProfRec* pr = prof_start(last ? T_UPDATE_LAST : T_UPDATE, st);
-      if (last)
-        hipLaunchKernelGGL(k_update<true>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M[0], ntri1, tu,
-                           y, raw, n, part, -1);
-      else
-        hipLaunchKernelGGL(k_update<false>, dim3(tu), dim3(MM_THREADS), 0, st, A, N, nblk, k, w.Wo, w.M[0], ntri1, tu,
-                           (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, -1);
-      prof_stop(pr, st);
-      CHECK_LAUNCH("k_update");
-    }
-  }
-  return 0;
-}
-
-extern "C" size_t gpsr_invert_workspace_bytes(int B, int n) {
-  if (B <= 0 || n <= 0) return 0;
-  return inv_ws_bytes(B, gpsr_padded_n(n));
-}
-
-extern "C" int gpsr_invert(double* A, int B, int n, double* logdet, int32_t* flags, void* workspace,
-                           size_t workspace_bytes, void* stream) {
-  if (B <= 0) return 0;
-  if (!A || !logdet || !flags || !workspace) return arg_fail("null pointer");
-  if (n % NB != 0) return arg_fail("gpsr_invert needs n == gpsr_padded_n(n)");
-  if (workspace_bytes < inv_ws_bytes(B, n)) return arg_fail("workspace too small");
-  hipStream_t st = (hipStream_t)stream;
-  hipError_t e = hipMemsetAsync(logdet, 0, (size_t)B * 8, st);
-  if (e != hipSuccess) return hip_fail(e, "memset logdet");
-  e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
-  if (e != hipSuccess) return hip_fail(e, "memset flags");
-  InvWs w = inv_ws_carve((char*)workspace, B, n);
-  return launch_sweeps(A, B, n, w, logdet, flags, st);
-}
-
-// ---------------------------------------------------------------- fit
+// ---------------------------------------------------------------- fit workspace
 struct FitWs {
   double* A; InvWs inv; double *stats1, *stats2, *logdet, *part; float *m1, *m2;
 };
@@ -273,11 +192,16 @@ static size_t part_bytes(int B, int nblk) {
   const int per = (nblk - 1) * nblk / 2 + nblk - 1;
   return align256((size_t)B * (per > 0 ? per : 1) * 2 * NB * 8);
 }
-static size_t fit_ws_bytes(int B, int N) {
+static size_t fit_ws_bytes1(int B, int N) {
   const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2;
   return align256((size_t)B * N * N * 8) + inv_ws_bytes(B, N) + align256((size_t)B * nblk * 4 * 8) +
          align256((size_t)B * ntri * 2 * 8) + align256((size_t)B * 8) + part_bytes(B, nblk) +
          2 * align256((size_t)B * 4 * 4);
+}
+// the fit may run its batch as two halves with a workspace each (run_dual)
+static size_t fit_ws_bytes(int B, int N) {
+  const size_t one = fit_ws_bytes1(B, N), two = fit_ws_bytes1((B + 1) / 2, N) + fit_ws_bytes1(B / 2 > 0 ? B / 2 : 1, N);
+  return one > two ? one : two;
 }
 static FitWs fit_ws_carve(char* base, int B, int N) {
   const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2;
@@ -297,6 +221,53 @@ extern "C" size_t gpsr_fit_workspace_bytes(int B, int n, int d) {
   (void)d;
   if (B <= 0 || n <= 0) return 0;
   return fit_ws_bytes(B, gpsr_padded_n(n));
+}
+
+// ---------------------------------------------------------------- launch sequence
+// One evaluation (covariance, blocked sweep, alpha, gradient statistics) and one fit are sequences of
+// launches over the same batch.  They are written down as a list of operations first and issued
+// afterwards, so that the same list can drive one batch on one stream or two half-batches on two streams.
+enum { OP_BUILD, OP_PIVOT, OP_PANEL, OP_UPD_SEL, OP_UPD2, OP_UPD, OP_GRAD1, OP_GRAD2, OP_ADAM };
+struct Op { int kind, k, set, arg; bool heavy; };   // set: which (U, M, Wo) triple; arg: OP_UPD last flag / OP_ADAM iteration
+
+struct Batch {   // one batch (or half-batch) of GPs and its buffers
+  int B;
+  const double *X, *y;
+  float* raw;
+  double *alpha, *loss;
+  float* grad;
+  int32_t* flags;
+  FitWs w;
+  hipStream_t st;
+};
+struct FitShape { int n, N, d, kid; float lr; bool with_part; };
+
+// pivots are taken two at a time while at least one single step remains for the end (the alpha epilogue
+// lives in the single-step kernel): nblk odd -> (nblk-1)/2 pairs + 1 single, even -> (nblk-2)/2 pairs + 2
+static void append_sweep_ops(std::vector<Op>& ops, int nblk, bool with_part) {
+  const int npairs = (g_pair_steps && nblk >= 3) ? (nblk - 1 - (nblk % 2 == 0 ? 1 : 0)) / 2 : 0;
+  int k = 0;
+  for (int m = 0; m < npairs; ++m, k += 2) {
+    ops.push_back({OP_PIVOT, k, 0, 0, false});
+    ops.push_back({OP_PANEL, k, 0, 0, false});
+    ops.push_back({OP_UPD_SEL, k, 0, 0, false});
+    ops.push_back({OP_PIVOT, k + 1, 1, 0, false});
+    ops.push_back({OP_PANEL, k + 1, 1, 0, false});
+    ops.push_back({OP_UPD2, k, 0, 0, true});
+  }
+  for (; k < nblk; ++k) {
+    ops.push_back({OP_PIVOT, k, 0, 0, false});
+    if (nblk > 1) {
+      ops.push_back({OP_PANEL, k, 0, 0, false});
+      ops.push_back({OP_UPD, k, 0, (k == nblk - 1 && with_part) ? 1 : 0, true});
+    }
+  }
+}
+static void append_eval_ops(std::vector<Op>& ops, int nblk, bool with_grad) {
+  ops.push_back({OP_BUILD, 0, 0, 0, true});
+  append_sweep_ops(ops, nblk, nblk > 1);   // alpha's mat-vec rides on the last update launch; one block: nothing to ride on
+  ops.push_back({OP_GRAD1, 0, 0, 0, false});
+  if (with_grad) ops.push_back({OP_GRAD2, 0, 0, 0, true});
 }
 
 static int launch_grad2(const FitWs& w, const double* X, const float* raw, const double* alpha, int B, int n,
@@ -322,30 +293,189 @@ static int launch_grad2(const FitWs& w, const double* X, const float* raw, const
   return 0;
 }
 
-// K build + inversion + alpha (+ gradient statistics when with_grad)
-static int eval_once(const FitWs& w, const double* X, const double* y, const float* raw, double* alpha,
-                     int32_t* flags, int B, int n, int N, int d, int kid, bool with_grad, hipStream_t st) {
-  int rc = launch_build(X, B, n, N, d, kid, raw, w.A, w.logdet, st, 0);   // diagonal tiles: lower sub-blocks only
-  if (rc) return rc;
-  const int nblk = N / NB;
-  const bool fused = nblk > 1;   // alpha's mat-vec rides on the last update launch; one block: nothing to ride on
-  rc = fused ? launch_sweeps(w.A, B, N, w.inv, w.logdet, flags, st, y, raw, n, w.part)
-             : launch_sweeps(w.A, B, N, w.inv, w.logdet, flags, st);
-  if (rc) return rc;
-  ProfRec* pr = prof_start(T_GRAD1, st);
-  if (fused) {
-    hipLaunchKernelGGL(k_grad1r, dim3(nblk, B), dim3(MM_THREADS), 0, st, w.A, N, n, nblk, nblk - 1, y, raw, w.part,
-                       (nblk - 1) * nblk / 2, alpha, w.stats1);
-  } else {
-    const size_t lds1 = (size_t)(N + 5 * NB + 32) * sizeof(double);
-    hipLaunchKernelGGL(k_grad1, dim3(nblk, B), dim3(MM_THREADS), lds1, st, w.A, N, n, nblk, y, raw, alpha, w.stats1);
+static int launch_op(const Op& op, const Batch& h, const FitShape& c) {
+  const int B = h.B, N = c.N, nblk = N / NB, ntri1 = (nblk - 1) * nblk / 2, ntri = nblk * (nblk + 1) / 2;
+  const FitWs& w = h.w;
+  hipStream_t st = h.st;
+  double* Wo = op.set ? w.inv.Wo2 : w.inv.Wo;
+  ProfRec* pr;
+  switch (op.kind) {
+    case OP_BUILD:
+      return launch_build(h.X, B, c.n, N, c.d, c.kid, h.raw, w.A, w.logdet, st, 0);   // diagonal tiles: lower sub-blocks only
+    case OP_PIVOT:
+      return launch_pivot(w.A, B, N, op.k, w.inv.U[op.set], w.inv.M[op.set], w.logdet, h.flags, st);
+    case OP_PANEL:
+      return launch_panel(w.A, B, N, op.k, w.inv.U[op.set], Wo, st);
+    case OP_UPD_SEL: {
+      const int tu = nblk * B;   // the tiles of block row / column k+1 only
+      pr = prof_start(T_UPDATE_SEL, st);
+      hipLaunchKernelGGL(k_update<false>, dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
+                         ntri1, tu, (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, op.k + 1);
+      prof_stop(pr, st);
+      CHECK_LAUNCH("k_update(sel)");
+      return 0;
+    }
+    case OP_UPD2: {
+      const int nb2 = nblk - 2, per = nb2 * (nb2 + 1) / 2 + nb2 + 1 + nblk - 1, tu = per * B;
+      pr = prof_start(T_UPDATE2, st);
+      hipLaunchKernelGGL(k_update2, dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.Wo2,
+                         w.inv.M[0], w.inv.M[1], tu);
+      prof_stop(pr, st);
+      CHECK_LAUNCH("k_update2");
+      return 0;
+    }
+    case OP_UPD: {
+      const int tu = (ntri1 + nblk - 1) * B;
+      pr = prof_start(op.arg ? T_UPDATE_LAST : T_UPDATE, st);
+      if (op.arg)
+        hipLaunchKernelGGL(k_update<true>, dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
+                           ntri1, tu, h.y, (const float*)h.raw, c.n, w.part, -1);
+      else
+        hipLaunchKernelGGL(k_update<false>, dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
+                           ntri1, tu, (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, -1);
+      prof_stop(pr, st);
+      CHECK_LAUNCH("k_update");
+      return 0;
+    }
+    case OP_GRAD1: {
+      pr = prof_start(T_GRAD1, st);
+      if (nblk > 1) {
+        hipLaunchKernelGGL(k_grad1r, dim3(nblk, B), dim3(MM_THREADS), 0, st, w.A, N, c.n, nblk, nblk - 1, h.y,
+                           (const float*)h.raw, w.part, ntri1, h.alpha, w.stats1);
+      } else {
+        const size_t lds1 = (size_t)(N + 5 * NB + 32) * sizeof(double);
+        hipLaunchKernelGGL(k_grad1, dim3(nblk, B), dim3(MM_THREADS), lds1, st, w.A, N, c.n, nblk, h.y,
+                           (const float*)h.raw, h.alpha, w.stats1);
+      }
+      prof_stop(pr, st);
+      CHECK_LAUNCH("k_grad1");
+      return 0;
+    }
+    case OP_GRAD2:
+      return launch_grad2(w, h.X, h.raw, h.alpha, B, c.n, N, c.d, c.kid, st);
+    case OP_ADAM: {
+      if (op.arg > 0) {   // Adam step number op.arg
+        const double b1 = 0.9, b2 = 0.999;
+        const double bc1 = 1.0 - pow(b1, op.arg), bc2 = 1.0 - pow(b2, op.arg);
+        const float step_size = (float)((double)c.lr / bc1);
+        const float bc2_sqrt = (float)sqrt(bc2);
+        hipLaunchKernelGGL(k_adam, dim3((B + 63) / 64), dim3(64), 0, st, h.raw, w.m1, w.m2, w.stats1, w.stats2, w.logdet,
+                           B, c.n, nblk, ntri, h.loss, (float*)nullptr, 1, step_size, bc2_sqrt, (float)(1.0 - b1),
+                           (float)b2, (float)(1.0 - b2), 1e-8f);
+      } else {            // evaluation only: loss and gradient out, no step
+        hipLaunchKernelGGL(k_adam, dim3((B + 63) / 64), dim3(64), 0, st, h.raw, w.m1, w.m2, w.stats1, w.stats2, w.logdet,
+                           B, c.n, nblk, ntri, h.loss, h.grad, 0, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f);
+      }
+      CHECK_LAUNCH("k_adam");
+      return 0;
+    }
   }
-  prof_stop(pr, st);
-  CHECK_LAUNCH("k_grad1");
-  if (with_grad) return launch_grad2(w, X, raw, alpha, B, n, N, d, kid, st);
+  return arg_fail("unknown op");
+}
+
+static int ensure_lds_attrs() {
+  static bool done = false;
+  if (!done) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_pivot, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)PIVOT_LDS_BYTES);
+    if (e != hipSuccess) return hip_fail(e, "pivot lds attr");
+    done = true;
+  }
   return 0;
 }
 
+static int run_single(const std::vector<Op>& ops, const Batch& h, const FitShape& c) {
+  int rc = ensure_lds_attrs();
+  for (size_t i = 0; i < ops.size() && !rc; ++i) rc = launch_op(ops[i], h, c);
+  return rc;
+}
+
+// Two half-batches on two streams (opt-in: gpsr_set_dual_stream).  The launches of one evaluation alternate
+// between kernels that fill the chip (covariance, the big updates, the gradient pass) and kernels that cannot
+// (k_pivot is a latency-bound chain on 2 workgroups per CU; k_panel and the 7-tile update are short): back to
+// back on one stream the latter leave part of the machine idle.  Two independent halves on two streams fill
+// some of those holes: measured 1030 -> 975 ms per Set14 x3 step.  Chaining the big kernels A, B, A, B with
+// events so that only small ones run underneath was tried and is slower (1009 ms): the small kernels starve
+// under a kernel that owns every workgroup slot.  Half A uses the caller's stream, half B a side stream forked
+// from and joined to it with events: the call stays asynchronous and ordered on the caller's stream as a whole.
+// Not the default: with overlapping launches a per-launch duration no longer measures one kernel (bench.py's
+// roofline), and the results are bit-identical either way.
+struct SideStream { hipStream_t s; hipEvent_t fork, join; bool ok; };
+static thread_local SideStream g_side[64] = {};
+static int g_dual_stream = 0;
+
+extern "C" int gpsr_set_dual_stream(int on) {
+  const int old = g_dual_stream;
+  g_dual_stream = on ? 1 : 0;
+  return old;
+}
+
+static SideStream* side_stream() {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  SideStream* ss = &g_side[dev];
+  if (!ss->ok) {
+    if (hipStreamCreateWithFlags(&ss->s, hipStreamNonBlocking) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
+    if (hipEventCreateWithFlags(&ss->join, hipEventDisableTiming) != hipSuccess) return nullptr;
+    ss->ok = true;
+  }
+  return ss;
+}
+
+static int run_dual(const std::vector<Op>& ops, const Batch& a, Batch b, const FitShape& c, SideStream* ss) {
+  int rc = ensure_lds_attrs();
+  if (rc) return rc;
+  hipError_t e;
+  b.st = ss->s;
+  if ((e = hipEventRecord(ss->fork, a.st)) != hipSuccess) return hip_fail(e, "fork record");
+  if ((e = hipStreamWaitEvent(b.st, ss->fork, 0)) != hipSuccess) return hip_fail(e, "fork wait");
+  // the host feeds the two streams alternately, one big launch (and the small ones before it) at a time
+  const size_t n = ops.size();
+  size_t ia = 0, ib = 0;
+  while (ia < n || ib < n) {
+    while (ia < n) {
+      const Op& op = ops[ia++];
+      if ((rc = launch_op(op, a, c))) return rc;
+      if (op.heavy) break;
+    }
+    while (ib < n) {
+      const Op& op = ops[ib++];
+      if ((rc = launch_op(op, b, c))) return rc;
+      if (op.heavy) break;
+    }
+  }
+  if ((e = hipEventRecord(ss->join, b.st)) != hipSuccess) return hip_fail(e, "join record");
+  if ((e = hipStreamWaitEvent(a.st, ss->join, 0)) != hipSuccess) return hip_fail(e, "join wait");
+  return 0;
+}
+
+extern "C" size_t gpsr_invert_workspace_bytes(int B, int n) {
+  if (B <= 0 || n <= 0) return 0;
+  return inv_ws_bytes(B, gpsr_padded_n(n));
+}
+
+extern "C" int gpsr_invert(double* A, int B, int n, double* logdet, int32_t* flags, void* workspace,
+                           size_t workspace_bytes, void* stream) {
+  if (B <= 0) return 0;
+  if (!A || !logdet || !flags || !workspace) return arg_fail("null pointer");
+  if (n % NB != 0) return arg_fail("gpsr_invert needs n == gpsr_padded_n(n)");
+  if (workspace_bytes < inv_ws_bytes(B, n)) return arg_fail("workspace too small");
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(logdet, 0, (size_t)B * 8, st);
+  if (e != hipSuccess) return hip_fail(e, "memset logdet");
+  e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
+  if (e != hipSuccess) return hip_fail(e, "memset flags");
+  Batch h = {};
+  h.B = B; h.flags = flags; h.st = st;
+  h.w.A = A; h.w.inv = inv_ws_carve((char*)workspace, B, n); h.w.logdet = logdet;
+  FitShape c = {n, n, 0, 0, 0.f, false};
+  std::vector<Op> ops;
+  append_sweep_ops(ops, n / NB, false);
+  return run_single(ops, h, c);
+}
+
+// ---------------------------------------------------------------- fit
 static int check_fit_args(const double* X, const double* y, int B, int n, int d, int kid, const void* ws,
                           size_t wsb) {
   if (!X || !y || !ws) return arg_fail("null pointer");
@@ -355,6 +485,8 @@ static int check_fit_args(const double* X, const double* y, int B, int n, int d,
   return 0;
 }
 
+#define DUAL_MIN_B 128   // below this a half-batch no longer fills the chip by itself
+
 extern "C" int gpsr_fit(const double* X, const double* y, int B, int n, int d, int kernel_id, float* raw,
                         int iters, float lr, double* alpha, double* loss, int32_t* flags, void* workspace,
                         size_t workspace_bytes, void* stream) {
@@ -363,26 +495,32 @@ extern "C" int gpsr_fit(const double* X, const double* y, int B, int n, int d, i
   if (rc) return rc;
   if (!raw || !alpha || !flags || iters < 0) return arg_fail("fit outputs");
   hipStream_t st = (hipStream_t)stream;
-  const int N = gpsr_padded_n(n), nblk = N / NB, ntri = nblk * (nblk + 1) / 2;
-  FitWs w = fit_ws_carve((char*)workspace, B, N);
-  hipError_t e = hipMemsetAsync(w.m1, 0, 2 * align256((size_t)B * 16), st);
-  if (e != hipSuccess) return hip_fail(e, "memset adam state");
-  e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
+  const int N = gpsr_padded_n(n), nblk = N / NB;
+  hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
   if (e != hipSuccess) return hip_fail(e, "memset flags");
-  const double b1 = 0.9, b2 = 0.999;
+  // `iters` Adam steps, then the final factorisation at the post-step hyper-parameters -> alpha
+  std::vector<Op> ops;
   for (int it = 1; it <= iters; ++it) {
-    rc = eval_once(w, X, y, raw, alpha, flags, B, n, N, d, kernel_id, true, st);
-    if (rc) return rc;
-    const double bc1 = 1.0 - pow(b1, it), bc2 = 1.0 - pow(b2, it);
-    const float step_size = (float)((double)lr / bc1);
-    const float bc2_sqrt = (float)sqrt(bc2);
-    hipLaunchKernelGGL(k_adam, dim3((B + 63) / 64), dim3(64), 0, st, raw, w.m1, w.m2, w.stats1, w.stats2, w.logdet,
-                       B, n, nblk, ntri, loss, (float*)nullptr, 1, step_size, bc2_sqrt, (float)(1.0 - b1),
-                       (float)b2, (float)(1.0 - b2), 1e-8f);
-    CHECK_LAUNCH("k_adam");
+    append_eval_ops(ops, nblk, true);
+    ops.push_back({OP_ADAM, 0, 0, it, false});
   }
-  // final factorisation at the post-step hyper-parameters -> alpha for the predictive mean
-  return eval_once(w, X, y, raw, alpha, flags, B, n, N, d, kernel_id, false, st);
+  append_eval_ops(ops, nblk, false);
+  FitShape c = {n, N, d, kernel_id, lr, nblk > 1};
+  SideStream* ss = (g_dual_stream && nblk > 1 && B >= 2 * DUAL_MIN_B) ? side_stream() : nullptr;
+  const int Ba = ss ? (B + 1) / 2 : B;
+  Batch a = {};
+  a.B = Ba; a.X = X; a.y = y; a.raw = raw; a.alpha = alpha; a.loss = loss; a.flags = flags; a.st = st;
+  a.w = fit_ws_carve((char*)workspace, Ba, N);
+  e = hipMemsetAsync(a.w.m1, 0, 2 * align256((size_t)Ba * 16), st);
+  if (e != hipSuccess) return hip_fail(e, "memset adam state");
+  if (!ss) return run_single(ops, a, c);
+  Batch b = {};
+  b.B = B - Ba; b.X = X + (size_t)Ba * n * d; b.y = y + (size_t)Ba * n; b.raw = raw + 4 * (size_t)Ba;
+  b.alpha = alpha + (size_t)Ba * N; b.loss = loss ? loss + Ba : nullptr; b.flags = flags + Ba;
+  b.w = fit_ws_carve((char*)workspace + fit_ws_bytes1(Ba, N), b.B, N);
+  e = hipMemsetAsync(b.w.m1, 0, 2 * align256((size_t)b.B * 16), st);   // on the caller's stream: before the fork
+  if (e != hipSuccess) return hip_fail(e, "memset adam state");
+  return run_dual(ops, a, b, c, ss);
 }
 
 extern "C" int gpsr_loss_grad(const double* X, const double* y, int B, int n, int d, int kernel_id,
@@ -393,17 +531,18 @@ extern "C" int gpsr_loss_grad(const double* X, const double* y, int B, int n, in
   if (rc) return rc;
   if (!raw || !loss || !grad || !flags) return arg_fail("loss_grad outputs");
   hipStream_t st = (hipStream_t)stream;
-  const int N = gpsr_padded_n(n), nblk = N / NB, ntri = nblk * (nblk + 1) / 2;
-  FitWs w = fit_ws_carve((char*)workspace, B, N);
+  const int N = gpsr_padded_n(n), nblk = N / NB;
   hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
   if (e != hipSuccess) return hip_fail(e, "memset flags");
-  double* alpha = w.inv.Wo;  // [B][N] fits in [B][NB][N]; Wo is dead after the sweeps
-  rc = eval_once(w, X, y, raw, alpha, flags, B, n, N, d, kernel_id, true, st);
-  if (rc) return rc;
-  hipLaunchKernelGGL(k_adam, dim3((B + 63) / 64), dim3(64), 0, st, (float*)raw, w.m1, w.m2, w.stats1, w.stats2,
-                     w.logdet, B, n, nblk, ntri, loss, grad, 0, 0.f, 1.f, 0.f, 0.f, 0.f, 0.f);
-  CHECK_LAUNCH("k_adam(eval)");
-  return 0;
+  Batch h = {};
+  h.B = B; h.X = X; h.y = y; h.raw = (float*)raw; h.loss = loss; h.grad = grad; h.flags = flags; h.st = st;
+  h.w = fit_ws_carve((char*)workspace, B, N);
+  h.alpha = h.w.inv.Wo;  // [B][N] fits in [B][NB][N]; Wo is dead after the sweeps
+  std::vector<Op> ops;
+  append_eval_ops(ops, nblk, true);
+  ops.push_back({OP_ADAM, 0, 0, 0, false});
+  FitShape c = {n, N, d, kernel_id, 0.f, nblk > 1};
+  return run_single(ops, h, c);
 }
 
 // ---------------------------------------------------------------- predict

@@ -104,6 +104,11 @@ def fit(X, y, kernel_id, raw, iters=50, lr=0.1, workspace=None, want_loss=False)
     return (alpha, flags, loss) if want_loss else (alpha, flags)
 
 
+def set_dual_stream(on):
+    """gpsr_set_dual_stream: two half-batches on two streams inside gpsr_fit (opt-in). Returns the previous setting."""
+    return bool(_lib.load().gpsr_set_dual_stream(1 if on else 0))
+
+
 def loss_grad(X, y, kernel_id, raw, workspace=None):
     lib = _lib.load()
     B, n, d = X.shape

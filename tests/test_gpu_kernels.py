@@ -235,3 +235,27 @@ def test_fit_constant_patch_rbf():
         pred = ops.predict(X, Xs, alpha, raw, kid)
         assert torch.isfinite(pred).all()
         assert (pred - 0.5).abs().max().item() < 1e-6
+
+
+def test_fit_dual_stream_bit_identical():
+    """gpsr_set_dual_stream: the batch as two half-batches on two streams gives the same bits
+    (per-GP arithmetic does not depend on the batch it runs in)."""
+    from super_resolution_amd import ops
+    B, n = 300, 324
+    rng = np.random.default_rng(5)
+    X = to_dev(rng.random((B, n, 8)))
+    y = to_dev(rng.random((B, n)))
+    raw0 = ops.init_hypers(y, ops.MATERN52)
+    outs = []
+    for dual in (False, True):
+        prev = ops.set_dual_stream(dual)
+        try:
+            raw = raw0.clone()
+            alpha, flags, loss = ops.fit(X, y, ops.MATERN52, raw, iters=3, want_loss=True)
+            torch.cuda.synchronize()
+            outs.append((alpha.clone(), raw.clone(), flags.clone(), loss.clone()))
+        finally:
+            ops.set_dual_stream(prev)
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
+    assert int(outs[0][2].sum()) == 0
