@@ -6,12 +6,15 @@
  * FFI of its own; each entry point below names the reference code it replaces
  * (file:line in the reference tree).  SURVEY.md 8(b) is the contract:
  *   - extern "C", plain pointers and sizes, no torch types;
- *   - every function returns int: 0 ok, <0 bad argument / HIP error,
- *     >0 number of GPs whose factorisation hit a non-positive pivot
- *     (details in the caller's flags[B]);
- *   - the caller owns every buffer (device pointers), including the workspace;
+ *   - every function returns int: 0 ok (launches enqueued), <0 bad argument / HIP error
+ *     (text in gpsr_last_error()).  Numerical failures are per GP and asynchronous: a GP
+ *     whose factorisation hits a non-positive pivot gets flags[b] != 0 in the caller's
+ *     flags[B]; gpsr_flag_count() is the one call that waits for the stream and returns
+ *     how many (the "positive return" of SURVEY.md 8(b));
+ *   - the caller owns every buffer (device pointers), including the workspace -- either
+ *     its own allocation or the one an opaque gpsr_ctx (gpsr_create / gpsr_destroy) holds;
  *   - every launch goes on the hipStream_t passed in (as void*); calls are
- *     asynchronous and never synchronise the device.
+ *     asynchronous and, gpsr_flag_count / gpsr_profile_end aside, never synchronise.
  *
  * Data are float64 images / features; hyper-parameters are the float32 RAW
  * (unconstrained) values GPyTorch keeps:  raw[b][0..3] =
@@ -49,6 +52,26 @@ const char* gpsr_version(void);
 
 /* Last HIP error text seen by this thread's most recent failing call. */
 const char* gpsr_last_error(void);
+
+/*
+ * Opaque context = a device and one workspace allocation sized for gpsr_fit /
+ * gpsr_predict_pixels of up to max_B GPs of up to max_n training points (d = 8 features),
+ * for callers that do not bring their own allocator.  gpsr_create makes
+ * device_id current and is the only allocating call of the library (one hipMalloc);
+ * gpsr_destroy frees it.  Pass gpsr_ctx_workspace() / gpsr_ctx_workspace_bytes() as the
+ * `workspace` arguments below.  One context per (device, stream): calls that share a
+ * workspace must be ordered on one stream.  Returns NULL on failure (gpsr_last_error()).
+ * No counterpart in the reference (GPyTorch allocates through torch).
+ */
+typedef struct gpsr_ctx gpsr_ctx;
+gpsr_ctx* gpsr_create(int device_id, int max_B, int max_n);
+void gpsr_destroy(gpsr_ctx* ctx);
+void* gpsr_ctx_workspace(const gpsr_ctx* ctx);
+size_t gpsr_ctx_workspace_bytes(const gpsr_ctx* ctx);
+
+/* Waits for `stream` and returns the number of non-zero entries of flags[B] (device
+ * pointer): the per-GP numerical failures of the calls enqueued before; <0 on error. */
+int gpsr_flag_count(const int32_t* flags, int B, void* stream);
 
 /* Padded matrix order used for n training points: n rounded up to GPSR_BLOCK. */
 int gpsr_padded_n(int n);

@@ -22,6 +22,11 @@ SIGNATURES = {
     "gpsr_version": (ctypes.c_char_p, []),
     "gpsr_last_error": (ctypes.c_char_p, []),
     "gpsr_padded_n": (c_int, [c_int]),
+    "gpsr_create": (c_void_p, [c_int, c_int, c_int]),
+    "gpsr_destroy": (None, [c_void_p]),
+    "gpsr_ctx_workspace": (c_void_p, [c_void_p]),
+    "gpsr_ctx_workspace_bytes": (c_size_t, [c_void_p]),
+    "gpsr_flag_count": (c_int, [c_void_p, c_int, c_void_p]),
     "gpsr_gather": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4),
     "gpsr_init_hypers": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "gpsr_covariance": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),

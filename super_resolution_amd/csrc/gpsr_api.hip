@@ -1,5 +1,5 @@
-// gpsr_api.hip -- C ABI (include/gpsr.h) over the gfx950 kernels.  No torch types,
-// no allocation: every buffer, the workspace included, belongs to the caller.
+// gpsr_api.hip -- C ABI (include/gpsr.h) over the gfx950 kernels.  No torch types; the only allocation is
+// the workspace of an optional gpsr_ctx (gpsr_create): every other buffer belongs to the caller.
 #include "gpsr_kernels.hpp"
 #include "../../include/gpsr.h"
 
@@ -543,6 +543,39 @@ extern "C" int gpsr_loss_grad(const double* X, const double* y, int B, int n, in
   ops.push_back({OP_ADAM, 0, 0, 0, false});
   FitShape c = {n, N, d, kernel_id, 0.f, nblk > 1};
   return run_single(ops, h, c);
+}
+
+// ---------------------------------------------------------------- context + flag count
+struct gpsr_ctx { int device; void* ws; size_t bytes; };
+
+extern "C" gpsr_ctx* gpsr_create(int device_id, int max_B, int max_n) {
+  if (max_B < 1 || max_n < 2 || gpsr_padded_n(max_n) > 16 * NB) { arg_fail("gpsr_create sizes"); return nullptr; }
+  hipError_t e = hipSetDevice(device_id);
+  if (e != hipSuccess) { hip_fail(e, "hipSetDevice"); return nullptr; }
+  gpsr_ctx* c = new gpsr_ctx{device_id, nullptr, gpsr_fit_workspace_bytes(max_B, max_n, 8)};
+  e = hipMalloc(&c->ws, c->bytes);
+  if (e != hipSuccess) { hip_fail(e, "hipMalloc(workspace)"); delete c; return nullptr; }
+  return c;
+}
+extern "C" void gpsr_destroy(gpsr_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipFree(ctx->ws);
+  delete ctx;
+}
+extern "C" void* gpsr_ctx_workspace(const gpsr_ctx* ctx) { return ctx ? ctx->ws : nullptr; }
+extern "C" size_t gpsr_ctx_workspace_bytes(const gpsr_ctx* ctx) { return ctx ? ctx->bytes : 0; }
+
+extern "C" int gpsr_flag_count(const int32_t* flags, int B, void* stream) {
+  if (!flags || B < 0) return arg_fail("gpsr_flag_count");
+  if (B == 0) return 0;
+  std::vector<int32_t> host((size_t)B);
+  hipError_t e = hipMemcpyAsync(host.data(), flags, (size_t)B * 4, hipMemcpyDeviceToHost, (hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "flag copy");
+  e = hipStreamSynchronize((hipStream_t)stream);
+  if (e != hipSuccess) return hip_fail(e, "flag sync");
+  int cnt = 0;
+  for (int b = 0; b < B; ++b) cnt += host[(size_t)b] != 0;
+  return cnt;
 }
 
 // ---------------------------------------------------------------- predict

@@ -259,3 +259,37 @@ def test_fit_dual_stream_bit_identical():
     for u, v in zip(outs[0], outs[1]):
         assert torch.equal(u, v)
     assert int(outs[0][2].sum()) == 0
+
+
+def test_context_workspace_and_flag_count():
+    """gpsr_create / gpsr_destroy: the library-owned workspace gives the same fit as a caller-owned one;
+    gpsr_flag_count is the synchronising read-out of the per-GP failure flags."""
+    from super_resolution_amd import _lib, ops
+    lib = _lib.load()
+    B, n = 5, 100
+    rng = np.random.default_rng(9)
+    X = to_dev(rng.random((B, n, 8)))
+    y = to_dev(rng.random((B, n)))
+    raw_a = ops.init_hypers(y, ops.RBF)
+    raw_b = raw_a.clone()
+    alpha_a, flags_a = ops.fit(X, y, ops.RBF, raw_a, iters=4)
+    ctx = lib.gpsr_create(torch.cuda.current_device(), B, n)
+    assert ctx, lib.gpsr_last_error()
+    try:
+        assert lib.gpsr_ctx_workspace_bytes(ctx) >= lib.gpsr_fit_workspace_bytes(B, n, 8)
+        N = ops.padded_n(n)
+        alpha_b = torch.empty((B, N), dtype=torch.float64, device=X.device)
+        flags_b = torch.empty(B, dtype=torch.int32, device=X.device)
+        st = torch.cuda.current_stream().cuda_stream
+        rc = lib.gpsr_fit(X.data_ptr(), y.data_ptr(), B, n, 8, ops.RBF, raw_b.data_ptr(), 4, 0.1, alpha_b.data_ptr(),
+                          None, flags_b.data_ptr(), lib.gpsr_ctx_workspace(ctx), lib.gpsr_ctx_workspace_bytes(ctx), st)
+        assert rc == 0
+        assert lib.gpsr_flag_count(flags_b.data_ptr(), B, st) == 0
+        assert torch.equal(alpha_a, alpha_b) and torch.equal(raw_a, raw_b)
+        flags_b[1] = 7
+        flags_b[3] = 1
+        assert lib.gpsr_flag_count(flags_b.data_ptr(), B, st) == 2
+    finally:
+        lib.gpsr_destroy(ctx)
+    assert lib.gpsr_create(torch.cuda.current_device(), 0, n) is None   # bad size: NULL + error text
+    assert b"gpsr_create" in lib.gpsr_last_error()
