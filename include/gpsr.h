@@ -114,6 +114,15 @@ int gpsr_covariance(const double* X, int B, int n, int d, int kernel_id,
                     const float* raw, double* K, void* stream);
 
 /*
+ * K2 with derivative: K as above (or NULL) and dK_dl[b] = outputscale * d k / d lengthscale
+ * (d k / d variance for the linear kernel), same layout, zero in the padding: the matrix
+ * whose trace against (K^-1 - alpha alpha^T) is the lengthscale gradient GPyTorch's autograd
+ * produces at gprsr.py:185.  The fit itself never materialises it (k_grad2 fuses it).
+ */
+int gpsr_covariance_grad(const double* X, int B, int n, int d, int kernel_id,
+                         const float* raw, double* K, double* dK_dl, void* stream);
+
+/*
  * In-place batched SPD inversion by blocked symmetric Gauss-Jordan sweeps
  * (MFMA f64 trailing updates).  On return A[b] holds -inv(A[b]) in the lower
  * block-triangle, logdet[b] = log det A[b].  Workspace: gpsr_invert_workspace_bytes.

@@ -30,6 +30,7 @@ SIGNATURES = {
     "gpsr_gather": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4),
     "gpsr_init_hypers": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
     "gpsr_covariance": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
+    "gpsr_covariance_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gpsr_invert_workspace_bytes": (c_size_t, [c_int, c_int]),
     "gpsr_invert": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "gpsr_fit_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),

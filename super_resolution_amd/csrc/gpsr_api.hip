@@ -146,6 +146,27 @@ extern "C" int gpsr_covariance(const double* X, int B, int n, int d, int kernel_
   return launch_build(X, B, n, gpsr_padded_n(n), d, kernel_id, raw, K, nullptr, (hipStream_t)stream, 1);
 }
 
+extern "C" int gpsr_covariance_grad(const double* X, int B, int n, int d, int kernel_id, const float* raw,
+                                    double* K, double* dK_dl, void* stream) {
+  if (B <= 0) return 0;
+  if (!X || !raw || !dK_dl) return arg_fail("null pointer");
+  if (n < 1 || d < 1 || d > 64 || kernel_id < 0 || kernel_id > 4) return arg_fail("covariance shape");
+  const int N = gpsr_padded_n(n), nblk = N / NB, ntri = nblk * (nblk + 1) / 2, total = ntri * B;
+  const size_t lds = build_lds(d);
+  hipStream_t st = (hipStream_t)stream;
+#define BDL(KK) hipLaunchKernelGGL((k_build_dl<KK>), dim3(total), dim3(256), lds, st, X, raw, K, dK_dl, n, N, d, ntri, total)
+  switch (kernel_id) {
+    case K_RBF: BDL(K_RBF); break;
+    case K_M12: BDL(K_M12); break;
+    case K_M32: BDL(K_M32); break;
+    case K_M52: BDL(K_M52); break;
+    default: BDL(K_LIN); break;
+  }
+#undef BDL
+  CHECK_LAUNCH("k_build_dl");
+  return 0;
+}
+
 // ---------------------------------------------------------------- inversion
 // Wo2 / U[1] / M[1]: second pivot of a two-pivot step (k_update2)
 struct InvWs { double *Wo, *Wo2, *U[2], *M[2]; };

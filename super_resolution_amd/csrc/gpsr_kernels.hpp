@@ -205,6 +205,43 @@ __global__ void k_build(const double* __restrict__ X, const float* __restrict__ 
   }
 }
 
+// Covariance and its derivative with respect to the lengthscale (variance for the linear kernel), for
+// callers and tests of the gradient: K as k_build writes it (may be null), dK[b] = outputscale * dk/dl in
+// the same lower block-triangle layout, zero in the identity padding.  Same launch shape as k_build.
+template <int KID>
+__global__ void k_build_dl(const double* __restrict__ X, const float* __restrict__ raw, double* __restrict__ A,
+                           double* __restrict__ dA, int n, int N, int d, int ntri, int total) {
+  extern __shared__ double sm[];
+  const int v = xcd_remap(blockIdx.x, total);
+  const int b = v / ntri, t = v % ntri;
+  int I, J; tri_decode(t, I, J);
+  const int ldx = d + 1;
+  double* xi = sm; double* xj = sm + NB * ldx;
+  const double* Xb = X + (size_t)b * n * d;
+  for (int e = threadIdx.x; e < NB * d; e += blockDim.x) {
+    int r = e / d, f = e % d;
+    int gi = I * NB + r, gj = J * NB + r;
+    xi[r * ldx + f] = gi < n ? Xb[(size_t)gi * d + f] : 0.0;
+    xj[r * ldx + f] = gj < n ? Xb[(size_t)gj * d + f] : 0.0;
+  }
+  const Hyp h = load_hyp(raw + 4 * b);
+  __syncthreads();
+  for (int e = threadIdx.x; e < NB * NB; e += blockDim.x) {
+    int i = e / NB, j = e % NB;
+    int gi = I * NB + i, gj = J * NB + j;
+    double kv = (gi == gj) ? 1.0 : 0.0, dk = 0.0;
+    if (gi < n && gj < n) {
+      const double st = pair_stat<KID>(xi + i * ldx, xj + j * ldx, d);
+      kern_val_dl<KID>(st, h, kv, dk);
+      kv = h.os * kv + (gi == gj ? h.noise : 0.0);
+      dk = h.os * dk;
+    }
+    const size_t off = (size_t)b * N * N + (size_t)gi * N + gj;
+    if (A) A[off] = kv;
+    dA[off] = dk;
+  }
+}
+
 // d == 8 fast path (the SRGPR feature vector): 448 threads; thread (g, j) = (tid / NB, tid % NB)
 // keeps column point x_j in registers and walks rows i = g, g+4, ...; the row point x_i
 // is an LDS broadcast (one address per wave, up to the g boundary).  Same per-element

@@ -69,6 +69,18 @@ def covariance(X, kernel_id, raw):
     return K
 
 
+def covariance_grad(X, kernel_id, raw):
+    """-> K, dK/dlengthscale (x outputscale), both [B,N,N] lower block-triangle (gpsr_covariance_grad)."""
+    lib = _lib.load()
+    B, n, d = X.shape
+    N = padded_n(n)
+    K = torch.zeros((B, N, N), dtype=torch.float64, device=X.device)
+    dK = torch.zeros((B, N, N), dtype=torch.float64, device=X.device)
+    _lib.check(lib.gpsr_covariance_grad(_p(X, torch.float64), B, n, d, kernel_id, _p(raw, torch.float32), _p(K),
+                                        _p(dK), _stream()), "gpsr_covariance_grad")
+    return K, dK
+
+
 def invert_(A):
     """In-place: A[b] <- -inv(A[b]) (lower block-triangle).  Returns logdet, flags."""
     lib = _lib.load()

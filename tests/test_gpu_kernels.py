@@ -293,3 +293,41 @@ def test_context_workspace_and_flag_count():
         lib.gpsr_destroy(ctx)
     assert lib.gpsr_create(torch.cuda.current_device(), 0, n) is None   # bad size: NULL + error text
     assert b"gpsr_create" in lib.gpsr_last_error()
+
+
+@pytest.mark.parametrize("kid", [0, 1, 2, 3, 4])
+def test_covariance_grad_matches_oracle_and_finite_difference(kid):
+    """gpsr_covariance_grad: dK/dl against the oracle's closed form and against a central difference
+    of gpsr_covariance itself in the (exactly representable, raw > 20) lengthscale."""
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(40 + kid)
+    B, n = 2, 130
+    X = rng.random((B, n, 8)) * 20.0
+    raw = (21.0 + 4 * rng.random((B, 4))).astype(np.float32)
+    K, dK = ops.covariance_grad(to_dev(X), kid, to_dev(raw))
+    K0 = ops.covariance(to_dev(X), kid, to_dev(raw))
+    assert torch.equal(K, K0)
+    dK = dK.cpu().numpy()
+    for b in range(B):
+        os_, ls = float(raw[b, 2]), float(raw[b, 3])
+        Xb = X[b]
+        if kid == ogp.LINEAR:
+            dk = Xb @ Xb.T                      # k = variance * <x, x'>: d k / d variance
+        else:
+            d2 = ((Xb[:, None, :] - Xb[None, :, :]) ** 2).sum(-1)
+            _, dk = ogp.kernel_and_dl(d2, ls, kid)
+        want = os_ * dk
+        got = dK[b][:n, :n]
+        lower = np.tril(np.ones((n, n), bool)) | (np.add.outer(np.arange(n) // 112, -(np.arange(n) // 112)) == 0)
+        assert np.abs(got - want)[lower].max() <= 1e-12 * max(1.0, np.abs(want).max())
+    # central difference in raw lengthscale (softplus(raw) == raw here, steps exact in float32)
+    h = 0.25
+    rp, rm = raw.copy(), raw.copy()
+    rp[:, 3] += h
+    rm[:, 3] -= h
+    Kp = ops.covariance(to_dev(X), kid, to_dev(rp)).cpu().numpy()
+    Km = ops.covariance(to_dev(X), kid, to_dev(rm)).cpu().numpy()
+    fd = (Kp - Km) / (2 * h)
+    blk = np.add.outer(np.arange(K.shape[1]) // 112, -(np.arange(K.shape[1]) // 112)) >= 0
+    scale = max(1e-30, np.abs(fd[:, blk]).max())
+    assert np.abs(fd - dK)[:, blk].max() <= 2e-3 * scale
