@@ -138,7 +138,7 @@ def _lower_blocks_to_full(M):
     return out
 
 
-@pytest.mark.parametrize("N", [112, 224, 336, 784])
+@pytest.mark.parametrize("N", [112, 224, 336, 448, 560, 784, 1120])   # 1..10 blocks: no pair, pairs + one or two single steps
 def test_invert_spd(N):
     from super_resolution_amd import ops
     rng = np.random.default_rng(N)
@@ -167,7 +167,7 @@ def test_invert_flags_non_spd():
 
 
 @pytest.mark.parametrize("kid,n,d", [(0, 324, 8), (1, 324, 8), (2, 324, 8), (3, 324, 8), (3, 784, 8), (3, 100, 8),
-                                     (4, 500, 49)])
+                                     (4, 500, 49), (2, 200, 8), (3, 420, 8), (0, 1024, 8)])
 def test_loss_and_grad_vs_autograd(kid, n, d):
     """d loss / d raw from the HIP closed form vs torch autograd through Cholesky (the reference's route)."""
     from super_resolution_amd import ops
