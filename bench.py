@@ -12,10 +12,11 @@ phases: gather -> 50-step Adam fit -> predictive mean -> recombination, plus
 the bicubic / blur / decimation stages between them), inputs resident in HBM as
 float64 images when the clock starts, uint8 HR images in HBM when it stops.
 
-N > 1 (weak scaling): the batch is N copies of the workload (different seeds);
+N > 1 (weak scaling, default): the batch is N copies of the workload (different seeds);
 the global patch list is sharded over the ranks (super_resolution_amd/dist.py)
 and the predicted patches are all-gathered over RCCL; value = all output
-megapixels / max-over-ranks time.
+megapixels / max-over-ranks time.  --scaling strong shards ONE copy instead
+(BASELINE config 4: --workload 4kx2 --scaling strong at 1/2/4/8 GPUs).
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
   roofline     : the dominant kernel (k_update2, f64 MFMA tile products), HIP-event timed
@@ -121,6 +122,9 @@ def main():
     ap.add_argument("--workload", default="set14x3")
     ap.add_argument("--kernel", default="matern52")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="N > 1: weak = N copies of the workload (default, the driver's scaling run); strong = ONE copy "
+                         "whose patches are sharded over the N ranks (BASELINE config 4: one 4K image at 1/2/4/8 GPUs)")
     ap.add_argument("--max-workspace-gb", type=float, default=48.0)
     ap.add_argument("--dual-stream", action="store_true",
                     help="gpsr_set_dual_stream(1): two half-batches on two streams (+5 %% throughput; per-launch "
@@ -141,7 +145,7 @@ def main():
     if a.workload == "4kx2" and a.kernel == "matern52":
         kern = K.matern32_kernel  # BASELINE.json config 4
     ops.set_dual_stream(a.dual_stream)
-    imgs_u8, s = workload(a.workload, world)
+    imgs_u8, s = workload(a.workload, world if a.scaling == "weak" else 1)
     out_px = sum(im.shape[0] * s * im.shape[1] * s for im in imgs_u8)
     n_patches = sum(patch_count(im.shape, s) for im in imgs_u8)
     g = GPRSR(s, kern, ColorSpace.GRAYSCALE, shard=(rank, world) if world > 1 else None,
@@ -211,8 +215,9 @@ def main():
     cpu = None
     if not a.no_cpu_baseline and world == 1:   # reported at N=1 only (rank 0 would stall the other ranks' exit)
         sec_per_fit, nfit, cores = cpu_baseline(g._gp.kernel_id, s)
-        fits = 2 * n_patches // world  # per copy of the workload
-        cpu_val = (out_px / world) / 1e6 / (sec_per_fit * fits)
+        copies = world if a.scaling == "weak" else 1
+        fits = 2 * n_patches // copies  # per copy of the workload
+        cpu_val = (out_px / copies) / 1e6 / (sec_per_fit * fits)
         cpu = {"value": round(cpu_val, 6), "unit": "output Mpx/s", "cores": cores, "kind": "port",
                "sample": f"{nfit} whole patch fits (n={n}, 50 Adam steps + predictive mean, m={(10 * s * s - 2) ** 2}) "
                          f"of the oracle's torch-f64 per-patch loop, {sec_per_fit:.2f} s/fit, extrapolated "
@@ -222,7 +227,7 @@ def main():
     line = {"metric": "output megapixels/sec (SR x3, Matern-5/2)" if (a.workload == "set14x3" and kname == "matern52")
             else f"output megapixels/sec ({a.workload}, {kname})",
             "value": round(value, 4), "unit": "Mpx/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
-            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": f"{a.workload}: {len(imgs_u8)} images, {n_patches} patches, "
                                    f"{2 * n_patches} GP fits (n={n}), {out_px / 1e6:.4f} output Mpx",
