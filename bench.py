@@ -84,7 +84,7 @@ def cpu_baseline(kernel_id, s, seconds_budget=20.0):
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
     p = 10 * s
-    lr = synthetic_lr(p + 4, p + 4, 77).astype(np.double) / 255.
+    lr = synthetic_lr(4 * p, 4 * p, 77).astype(np.double) / 255.   # 25+ patches: the time budget, not the image, ends the sample
     hi = cvops.resize_cubic(lr, fx=s, fy=s)
     locs = opatch.patch_locations(lr.shape, p)
     t0, done = time.time(), 0
