@@ -174,7 +174,8 @@ def main():
     dt = time.perf_counter() - t0
     prof = ops.profile_end() if rank == 0 else None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        t = torch.tensor([dt], dtype=torch.float64,
+                         device=dev if torch.distributed.get_backend() == "nccl" else "cpu")   # gloo: one-GPU rehearsal
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     flags_bad = int(sum(int(f.sum()) for f in g.stats.flags))

@@ -29,8 +29,14 @@ def all_gather_rows(local, B, world, group=None, force_collective=False):
     tail = local.shape[1:]
     buf = torch.zeros((cap,) + tuple(tail), dtype=local.dtype, device=local.device)
     buf[:local.shape[0]] = local
-    parts = [torch.empty_like(buf) for _ in range(world)]
-    dist.all_gather(parts, buf, group=group)
+    if dist.get_backend(group) == "gloo" and buf.is_cuda:   # rehearsal path: gloo moves host memory
+        hbuf = buf.cpu()
+        hparts = [torch.empty_like(hbuf) for _ in range(world)]
+        dist.all_gather(hparts, hbuf, group=group)
+        parts = [p.to(buf.device) for p in hparts]
+    else:
+        parts = [torch.empty_like(buf) for _ in range(world)]
+        dist.all_gather(parts, buf, group=group)
     out = torch.empty((B,) + tuple(tail), dtype=local.dtype, device=local.device)
     for r in range(world):
         lo, hi = shard_range(B, r, world)
@@ -44,6 +50,12 @@ def init_from_env(backend=None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box: GPSR_LOCAL_DEVICE=0 puts every rank on that device and
+    # GPSR_DIST_BACKEND=gloo carries the collectives (RCCL refuses two ranks on one GPU)
+    if "GPSR_LOCAL_DEVICE" in os.environ:
+        local = int(os.environ["GPSR_LOCAL_DEVICE"])
+    if backend is None and "GPSR_DIST_BACKEND" in os.environ:
+        backend = os.environ["GPSR_DIST_BACKEND"]
     if world > 1 and not dist.is_initialized():
         if backend is None:
             backend = "nccl" if torch.cuda.is_available() else "gloo"

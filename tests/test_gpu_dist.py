@@ -39,3 +39,41 @@ def test_rccl_all_gather_single_rank():
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     r = subprocess.run([sys.executable, "-c", CHILD % ROOT], capture_output=True, text=True, timeout=300, env=env)
     assert r.returncode == 0 and "rccl-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+CHILD2 = r"""
+import os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from super_resolution_amd import dist as gdist, kernels as K, ops
+from super_resolution_amd.gprsr import GPRSR, ColorSpace
+from test_gpu_kernels import natural_image
+rank, world, local = gdist.init_from_env()
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+imgs = [np.rint(natural_image(H, W, s) * 255).astype(np.uint8) for H, W, s in ((44, 40, 1), (47, 52, 2), (40, 41, 3))]
+dimgs = [ops.u8_to_unit(torch.as_tensor(im).to(dev)) for im in imgs]
+sharded = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, shard=(rank, world)).apply_for_channel_device(dimgs)
+if rank == 0:
+    whole = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE).apply_for_channel_device(dimgs)
+    assert all(torch.equal(a, b) for a, b in zip(sharded, whole)), "sharded != unsharded"
+    sys.stdout.write("shard-ok\n")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_sharded_equals_unsharded(tmp_path):
+    """The whole sharded path on the device (gather of a slice, HIP fit, all-gather, recombination on every
+    rank) with two ranks sharing the box's one GPU; the collectives ride on gloo for this rehearsal (RCCL
+    refuses two ranks on one device), everything else is the production path.  Bit-identical to one rank."""
+    script = tmp_path / "child2.py"
+    script.write_text(CHILD2 % (ROOT, ROOT))
+    env = dict(os.environ)
+    env.update(GPSR_LOCAL_DEVICE="0", GPSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "shard-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
