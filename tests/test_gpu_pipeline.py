@@ -276,3 +276,30 @@ def test_non_finite_patch_raises_like_the_reference():
     g.check_failures = False
     out = g.apply_for_channel_device([to_dev(lr)])[0]
     assert out.shape == (88, 80)
+
+
+@pytest.mark.parametrize("H,W", [(20, 20), (20, 37), (33, 21)])
+def test_edge_geometries_vs_oracle(H, W):
+    """Smallest legal images: one distinct patch (H = W = p, four times over), one patch row, duplicate patch locations
+    (min(r, H-p) maps several grid points to the same corner, image_patches.py:31-41 keeps them)."""
+    from super_resolution_amd import ops
+    from super_resolution_amd.gprsr import GPRSR, ColorSpace
+    from super_resolution_amd.image_patches import PatchHandler
+    lr = _lr_image(H, W, H + W)
+    locs = PatchHandler([np.zeros((H, W)), np.zeros((2 * H, 2 * W))], base_patch_size=20).patch_locations
+    assert len(locs) >= 1
+    if (H, W) == (20, 20):
+        assert [tuple(l) for l in locs] == [(0, 0)] * 4    # range(0, 20, 16) = [0, 16], both clamped to 0
+    assert len(set(map(tuple, locs))) < len(locs)          # duplicates really occur here
+    want = osr.OracleGPRSR(2, ogp.RBF, "GRAYSCALE", chain=False).apply_for_channel_float(lr)
+    g = GPRSR(2, _kernels()[0], ColorSpace.GRAYSCALE)
+    got = g.apply_for_channel_device([ops.u8_to_unit(to_dev(lr))])[0].cpu().numpy()
+    assert got.shape == want.shape == (2 * H, 2 * W)
+    assert np.abs(got - want).max() < 2e-3 / 255
+
+
+def test_patch_larger_than_image_is_rejected():
+    """gprsr.py asserts through PatchHandler (image_patches.py:18-20): same failure mode here."""
+    from super_resolution_amd.gprsr import GPRSR, ColorSpace
+    with pytest.raises(AssertionError):
+        GPRSR(2, _kernels()[0], ColorSpace.GRAYSCALE).apply_for_channel(_lr_image(19, 30, 1))
