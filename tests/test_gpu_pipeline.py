@@ -303,3 +303,29 @@ def test_patch_larger_than_image_is_rejected():
     from super_resolution_amd.gprsr import GPRSR, ColorSpace
     with pytest.raises(AssertionError):
         GPRSR(2, _kernels()[0], ColorSpace.GRAYSCALE).apply_for_channel(_lr_image(19, 30, 1))
+
+
+def test_main_cli_end_to_end(golden_dir, tmp_path, capsys):
+    """main.py (README.md:22 of the reference names it) over a Set14-shaped folder: reads
+    *_LR.png, writes *_GPR_matern52_gray.png, --evaluate prints the PSNR/SSIM lines of
+    evaluation.py.  The written image must be the committed oracle output to one grey level."""
+    import shutil
+    from PIL import Image
+    import main
+    src = os.path.join(golden_dir, "set14_x3")
+    dst = tmp_path / "Set14" / "image_SRF_3"
+    dst.mkdir(parents=True)
+    nums = [5, 6]
+    for i in nums:
+        shutil.copy(f"{src}/lr_{i:03d}.png", dst / f"img_{i:03d}_SRF_3_LR.png")
+        shutil.copy(f"{src}/hr_{i:03d}.png", dst / f"img_{i:03d}_SRF_3_HR.png")
+    rc = main.main(["--srf", "3", "--kernel", "matern52", "--color-space", "grayscale", "--images", "5,6",
+                    "--dataset-dir", str(tmp_path / "Set14"), "--batch-images", "--evaluate"])
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert "Average - PSNR:" in out and "Upscaling 2 images took" in out
+    for i in nums:
+        got = np.array(Image.open(dst / f"img_{i:03d}_SRF_3_GPR_matern52_gray.png"))
+        want = np.array(Image.open(f"{src}/oracle_m52_{i:03d}.png"))
+        assert got.ndim == 3 and np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
+        assert np.abs(got[..., 0].astype(int) - want.astype(int)).max() <= 1
