@@ -84,7 +84,7 @@ int gpsr_padded_n(int n);
  *   locs  : [B][2] int32 (row, col) LR patch corners (PatchHandler.patch_locations)
  *   tidx  : [nt] int32 per-axis training indices inside the LR patch
  *           (range(1,p-1), or the grid of gprsr.py:140); n = nt*nt
- *   X  : [B][n][8]   y : [B][n]   Xs : [B][m][8],  m = (p*s-2)^2
+ *   X  : [B][n][8]   y : [B][n]   Xs : [B][m][8],  m = (p*s-2)^2   (X, Xs 16-byte aligned)
  * Feature order is that of gprsr.py:35.
  */
 int gpsr_gather(const double* train_in, const double* train_tgt, const double* test_in,

@@ -87,8 +87,9 @@ extern "C" int gpsr_gather(const double* train_in, const double* train_tgt, cons
   if (B <= 0) return 0;
   if (!train_in || !train_tgt || !test_in || !locs || !tidx || !X || !y || !Xs) return arg_fail("null pointer");
   if (p < 3 || s < 1 || p > H || p > W || nt < 1 || nt > p - 2) return arg_fail("patch geometry");
+  if ((((uintptr_t)X) | ((uintptr_t)Xs)) & 15) return arg_fail("X and Xs must be 16-byte aligned");
   const int n = nt * nt, m = (p * s - 2) * (p * s - 2);
-  const int total = 9 * n + 8 * m;
+  const int total = 5 * n + 4 * m;   // 16-byte work units, see k_gather
   int gx = (total + 255) / 256; if (gx > 64) gx = 64;
   hipLaunchKernelGGL(k_gather, dim3(gx, B), dim3(256), 0, (hipStream_t)stream, train_in, train_tgt, test_in,
                      H, W, s, p, locs, tidx, nt, X, y, Xs);
@@ -638,10 +639,12 @@ extern "C" int gpsr_combine(const double* pred, const double* test_in, int H, in
                             const int32_t* rows, int nr, const int32_t* cols, int nc, int mode, int clip,
                             double* out, void* stream) {
   if (!pred || !rows || !cols || !out) return arg_fail("null pointer");
-  if (nr < 1 || nc < 1 || p < 3 || s < 1 || (mode != 0 && mode != 1)) return arg_fail("combine geometry");
-  const size_t total = (size_t)H * s * W * s;
-  hipLaunchKernelGGL(k_combine, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, pred,
-                     test_in, H, W, s, p, rows, nr, cols, nc, mode, clip, out);
+  if (nr < 1 || nc < 1 || p < 3 || s < 1 || H < 1 || W < 1 || (mode != 0 && mode != 1)) return arg_fail("combine geometry");
+  const int Hs = H * s, Ws = W * s;
+  const size_t lds = (size_t)((nr + 31) / 32 + (nc + 31) / 32) * sizeof(uint32_t);
+  if ((Hs + CMB_TH - 1) / CMB_TH > 65535 || lds > 48 * 1024) return arg_fail("combine: image or patch grid too large");
+  hipLaunchKernelGGL(k_combine, dim3((Ws + CMB_TW - 1) / CMB_TW, (Hs + CMB_TH - 1) / CMB_TH), dim3(CMB_TH * CMB_TW), lds,
+                     (hipStream_t)stream, pred, test_in, H, W, s, p, rows, nr, cols, nc, mode, clip, out);
   CHECK_LAUNCH("k_combine");
   return 0;
 }

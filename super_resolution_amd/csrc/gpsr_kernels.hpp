@@ -106,6 +106,9 @@ __global__ void k_make_locs(const int* __restrict__ rows, const int* __restrict_
 }
 
 // ---------------------------------------------------------------- K1 gather
+// One 16-byte store per lane: a work unit is a PAIR of neighbour features of one point (the
+// reference's order gprsr.py:35 is four pairs of opposite neighbours: (+1,0)/(-1,0), (0,+1)/(0,-1),
+// (+1,+1)/(-1,-1), (+1,-1)/(-1,+1)), or one training target.  Units per patch: 4n + n + 4m.
 __global__ void k_gather(const double* __restrict__ tin, const double* __restrict__ ttg,
                          const double* __restrict__ tst, int H, int W, int s, int p,
                          const int32_t* __restrict__ locs, const int32_t* __restrict__ tidx, int nt,
@@ -113,23 +116,28 @@ __global__ void k_gather(const double* __restrict__ tin, const double* __restric
   const int b = blockIdx.y;
   const int r0 = locs[2 * b], c0 = locs[2 * b + 1];
   const int n = nt * nt, P = p * s, ms = P - 2, m = ms * ms, Ws = W * s;
-  const int dy[8] = {1, -1, 0, 0, 1, -1, 1, -1};
-  const int dx[8] = {0, 0, 1, -1, 1, -1, -1, 1};
-  const int total = 9 * n + 8 * m;
-  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
-    if (e < 8 * n) {
-      int q = e >> 3, f = e & 7;
-      int yy = tidx[q / nt], xx = tidx[q % nt];
-      X[(size_t)b * n * 8 + e] = tin[(size_t)(r0 + yy + dy[f]) * W + c0 + xx + dx[f]];
-    } else if (e < 9 * n) {
-      int q = e - 8 * n;
-      int yy = tidx[q / nt], xx = tidx[q % nt];
+  const int total = 5 * n + 4 * m;
+  for (int u = blockIdx.x * blockDim.x + threadIdx.x; u < total; u += gridDim.x * blockDim.x) {
+    if (u >= 4 * n && u < 5 * n) {
+      const int q = u - 4 * n;
+      const int yy = tidx[q / nt], xx = tidx[q % nt];
       y[(size_t)b * n + q] = ttg[(size_t)(r0 + yy) * W + c0 + xx];
+      continue;
+    }
+    const bool test = u >= 5 * n;
+    const int v = test ? u - 5 * n : u;
+    const int q = v >> 2, h = v & 3;
+    const int dyA = (h != 1) ? 1 : 0, dxA = (h == 0) ? 0 : (h == 3 ? -1 : 1);
+    if (!test) {
+      const int yy = tidx[q / nt], xx = tidx[q % nt];
+      const double* c = tin + (size_t)(r0 + yy) * W + c0 + xx;
+      const int o = dyA * W + dxA;
+      *(double2*)(X + (size_t)b * n * 8 + 2 * (size_t)v) = make_double2(c[o], c[-o]);
     } else {
-      int e2 = e - 9 * n;
-      int q = e2 >> 3, f = e2 & 7;
-      int yy = 1 + q / ms, xx = 1 + q % ms;
-      Xs[(size_t)b * m * 8 + e2] = tst[(size_t)(r0 * s + yy + dy[f]) * Ws + c0 * s + xx + dx[f]];
+      const int yy = 1 + q / ms, xx = 1 + q % ms;
+      const double* c = tst + (size_t)(r0 * s + yy) * Ws + c0 * s + xx;
+      const int o = dyA * Ws + dxA;
+      *(double2*)(Xs + (size_t)b * m * 8 + 2 * (size_t)v) = make_double2(c[o], c[-o]);
     }
   }
 }
@@ -1362,49 +1370,83 @@ k_predict(const double* __restrict__ X, const double* __restrict__ Xs, const dou
 }
 
 // ---------------------------------------------------------------- K6 combine
-// one thread per HR pixel; contributions are added in patch order (row-major over rows x cols)
-__global__ void k_combine(const double* __restrict__ pred, const double* __restrict__ tst, int H, int W,
-                          int s, int p, const int32_t* __restrict__ rows, int nr,
-                          const int32_t* __restrict__ cols, int nc, int mode, int clip,
-                          double* __restrict__ out) {
+// One thread per HR pixel, one workgroup per 8 x 32 pixel tile.  The workgroup first marks, in two
+// LDS bit masks, the patch rows / patch columns whose window touches its tile (any order of
+// rows[] / cols[] is accepted); a pixel then walks only the set bits, in ascending patch index,
+// so contributions are added in patch order (row-major over rows x cols) like the reference's loop.
+// dynamic LDS = (ceil(nr/32) + ceil(nc/32)) words.
+#define CMB_TH 8
+#define CMB_TW 32
+__global__ void __launch_bounds__(CMB_TH * CMB_TW)
+k_combine(const double* __restrict__ pred, const double* __restrict__ tst, int H, int W,
+          int s, int p, const int32_t* __restrict__ rows, int nr,
+          const int32_t* __restrict__ cols, int nc, int mode, int clip,
+          double* __restrict__ out) {
+  extern __shared__ uint32_t cmask_sm[];
   const int Hs = H * s, Ws = W * s, P = p * s, ms = P - 2;
-  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (idx >= (size_t)Hs * Ws) return;
-  const int R = (int)(idx / Ws), C = (int)(idx % Ws);
+  const int nrw = (nr + 31) >> 5, ncw = (nc + 31) >> 5;
+  uint32_t* rmask = cmask_sm;
+  uint32_t* cmask = cmask_sm + nrw;
+  const int tid = threadIdx.x;
+  const int R0 = blockIdx.y * CMB_TH, C0 = blockIdx.x * CMB_TW;
+  for (int w = tid; w < nrw + ncw; w += CMB_TH * CMB_TW) cmask_sm[w] = 0u;
+  __syncthreads();
+  for (int e = tid; e < nr; e += CMB_TH * CMB_TW) {
+    const int x = rows[e] * s;
+    if (x < R0 + CMB_TH && x + P > R0) atomicOr(&rmask[e >> 5], 1u << (e & 31));
+  }
+  for (int e = tid; e < nc; e += CMB_TH * CMB_TW) {
+    const int y = cols[e] * s;
+    if (y < C0 + CMB_TW && y + P > C0) atomicOr(&cmask[e >> 5], 1u << (e & 31));
+  }
+  __syncthreads();
+  const int R = R0 + tid / CMB_TW, C = C0 + tid % CMB_TW;
+  if (R >= Hs || C >= Ws) return;
+  const size_t idx = (size_t)R * Ws + C;
   double acc = 0.0, wsum = 0.0;
   const bool full = (tst == nullptr);  // pred holds whole [P][P] patches, rim included
   const double pix = full ? 0.0 : tst[idx];
   const size_t m = (size_t)ms * ms;
-  for (int ir = 0; ir < nr; ++ir) {
-    const int x = rows[ir] * s;
-    const int i = R - x;
-    if (i < 0 || i >= P) continue;
-    const int xs_ = (x == 0) ? 0 : 1;
-    const int xe = (x + P == Hs) ? P : P - 1;
-    if (i < xs_ || i >= xe) continue;
-    for (int ic = 0; ic < nc; ++ic) {
-      const int y = cols[ic] * s;
-      const int j = C - y;
-      if (j < 0 || j >= P) continue;
-      const int ys_ = (y == 0) ? 0 : 1;
-      const int ye = (y + P == Ws) ? P : P - 1;
-      if (j < ys_ || j >= ye) continue;
-      double v;
-      if (full)
-        v = pred[(size_t)(ir * nc + ic) * P * P + (size_t)i * P + j];
-      else if (i >= 1 && i <= P - 2 && j >= 1 && j <= P - 2)
-        v = pred[(size_t)(ir * nc + ic) * m + (size_t)(i - 1) * ms + (j - 1)];
-      else
-        v = pix;
-      if (mode == 0) {
-        acc = __dadd_rn(acc, v);
-        wsum = __dadd_rn(wsum, 1.0);
-      } else {
-        double vw = 1.0 - fabs(0.5 - (double)i / (double)P);
-        double hw = 1.0 - fabs(0.5 - (double)j / (double)P);
-        double w = __dmul_rn(vw, hw);
-        acc = __dadd_rn(acc, __dmul_rn(v, w));
-        wsum = __dadd_rn(wsum, w);
+  for (int wr = 0; wr < nrw; ++wr) {
+    uint32_t rb = rmask[wr];
+    while (rb) {
+      const int ir = (wr << 5) + __ffs(rb) - 1;
+      rb &= rb - 1;
+      const int x = rows[ir] * s;
+      const int i = R - x;
+      if (i < 0 || i >= P) continue;
+      const int xs_ = (x == 0) ? 0 : 1;
+      const int xe = (x + P == Hs) ? P : P - 1;
+      if (i < xs_ || i >= xe) continue;
+      for (int wc = 0; wc < ncw; ++wc) {
+        uint32_t cb = cmask[wc];
+        while (cb) {
+          const int ic = (wc << 5) + __ffs(cb) - 1;
+          cb &= cb - 1;
+          const int y = cols[ic] * s;
+          const int j = C - y;
+          if (j < 0 || j >= P) continue;
+          const int ys_ = (y == 0) ? 0 : 1;
+          const int ye = (y + P == Ws) ? P : P - 1;
+          if (j < ys_ || j >= ye) continue;
+          double v;
+          if (full)
+            v = pred[(size_t)(ir * nc + ic) * P * P + (size_t)i * P + j];
+          else if (i >= 1 && i <= P - 2 && j >= 1 && j <= P - 2)
+            v = pred[(size_t)(ir * nc + ic) * m + (size_t)(i - 1) * ms + (j - 1)];
+          else
+            v = pix;
+          if (mode == 0) {
+            acc = __dadd_rn(acc, v);
+            wsum = __dadd_rn(wsum, 1.0);
+          } else {
+            double vw = 1.0 - fabs(0.5 - (double)i / (double)P);
+            double hw = 1.0 - fabs(0.5 - (double)j / (double)P);
+            double w = __dmul_rn(vw, hw);
+            acc = __dadd_rn(acc, __dmul_rn(v, w));
+            wsum = __dadd_rn(wsum, w);
+          }
+        }
       }
     }
   }
