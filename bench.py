@@ -194,23 +194,30 @@ def main():
     n = (10 * s - 2) ** 2
     N = -(-n // NB) * NB
     B_local = -(-n_patches // world)
+    # A launch covers the whole local batch unless the engine cut it into workspace-sized chunks (4kx2) or the
+    # dual-stream scheduler into halves: GPs per launch = local batch x launches a whole-batch run would make / launches
+    # made.  Whole-batch launches per step: 2 phases x 51 evaluations (50 Adam steps + the final one) x passes per sweep.
+    nblk = N // NB
     if prof.get("update2", (0, 0.0))[0]:
         kname_dom, (cnt, ms) = "k_update2", prof["update2"]
         R = N - 2 * NB
-        flops_launch = B_local * (R * R * 2 * NB + 3 * R * NB * NB + NB ** 3 + (N - NB) * NB * NB)
-        if a.dual_stream:
-            flops_launch //= 2   # each launch covers a half-batch
+        flops_gp = R * R * 2 * NB + 3 * R * NB * NB + NB ** 3 + (N - NB) * NB * NB
+        passes = (nblk - 1) // 2 if nblk % 2 else (nblk - 2) // 2
     else:
         kname_dom, (cnt, ms) = "k_update", prof["update"]
-        flops_launch = B_local * ((N - NB) ** 2 * NB + (N - NB) * NB * NB)
+        flops_gp = (N - NB) ** 2 * NB + (N - NB) * NB * NB
+        passes = nblk
+    gps_per_launch = B_local * (2 * (g.iters + 1) * passes * a.steps) / cnt if cnt else 0.0
+    flops_launch = int(gps_per_launch * flops_gp)
     avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
     achieved = flops_launch / avg_s / 1e12 if cnt else float("nan")
     kernel_ms = {k: round(v[1] / a.steps, 3) for k, v in prof.items()}
     roofline = {"kernel": kname_dom, "bound": "mfma", "achieved": round(achieved, 3),
                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic(kname_dom, a.workload, B_local, N),
+                "traffic": pmc_traffic(kname_dom, a.workload, int(round(gps_per_launch)), N),
                 "traffic_note": "HBM bytes per launch, profiles/r01_pmc_invert_633x784.json (separate rocprofv3 --pmc passes)",
-                "launches_per_step": cnt // max(1, a.steps), "avg_launch_ms": round(avg_s * 1e3, 4),
+                "launches_per_step": cnt // max(1, a.steps), "gps_per_launch": round(gps_per_launch, 1),
+                "avg_launch_ms": round(avg_s * 1e3, 4),
                 "flops_per_launch": flops_launch, "kernel_ms_per_step": kernel_ms}
 
     cpu = None

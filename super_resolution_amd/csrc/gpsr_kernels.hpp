@@ -42,30 +42,75 @@ __device__ __forceinline__ Hyp load_hyp(const float* __restrict__ raw) {
   return h;
 }
 
+// ---- lean f64 sqrt / exp for the pair loops (k_build8, k_grad2_8, k_predict are bound by the f64 VALU issue
+// rate; libm's versions spend a third of their instructions on range scaling and special cases that cannot occur
+// here, and the compiler turns every Horner step on a constant into v_mov_b64 + v_fmac_f64).
+// d = a*b + c as one VOP3 instruction, c (a constant) read from an SGPR pair.
+__device__ __forceinline__ double fma_sc(double a, double b, double c) {
+  double d;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(c));
+  return d;
+}
+
+// sqrt(x) for x in [1e-30, 1e300]: v_rsq_f64 seed (2^-23 relative), one coupled Newton step (2^-46) and one
+// residual correction (< 1 ulp); libm's exponent scaling and its second correction (exact rounding) are left out.
+__device__ __forceinline__ double sqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  double g = x * y, h = 0.5 * y;
+  const double r = fma(-h, g, 0.5);
+  g = fma(g, r, g);
+  h = fma(h, r, h);
+  const double d = fma(-g, g, x);
+  return fma(d, h, g);
+}
+
+// exp(-s) for s >= 0 (anything above 800 gives 0): n = rint(-s log2 e), r = -s - n ln2 in two pieces,
+// degree-13 Taylor polynomial on |r| <= ln2/2 (truncation 4e-18 relative), ldexp.  < 1 ulp.
+__device__ __forceinline__ double exp_neg(double s) {
+  s = fmin(s, 800.0);
+  const double n = __builtin_rint(s * -1.4426950408889634);
+  double r = fma(n, -6.93147180369123816490e-01, -s);
+  r = fma(n, -1.90821492927058770002e-10, r);
+  double p = fma_sc(r, 1.6059043836821613e-10, 2.08767569878681e-09);   // 1/13!, 1/12!
+  p = fma_sc(p, r, 2.505210838544172e-08);    // 1/11!
+  p = fma_sc(p, r, 2.755731922398589e-07);    // 1/10!
+  p = fma_sc(p, r, 2.7557319223985893e-06);   // 1/9!
+  p = fma_sc(p, r, 2.48015873015873e-05);     // 1/8!
+  p = fma_sc(p, r, 1.984126984126984e-04);    // 1/7!
+  p = fma_sc(p, r, 1.388888888888889e-03);    // 1/6!
+  p = fma_sc(p, r, 8.333333333333333e-03);    // 1/5!
+  p = fma_sc(p, r, 4.1666666666666664e-02);   // 1/4!
+  p = fma_sc(p, r, 1.6666666666666666e-01);   // 1/3!
+  p = fma_sc(p, r, 0.5);
+  p = fma_sc(p, r, 1.0);
+  p = fma_sc(p, r, 1.0);
+  return ldexp(p, (int)n);
+}
+
 // base kernel value from the pair statistic (squared distance, or dot product for linear)
 template <int KID>
 __device__ __forceinline__ double kern_val(double st, const Hyp& h) {
   if (KID == K_LIN) return h.ls * st;
-  if (KID == K_RBF) return exp(-0.5 * st * h.il2);
-  double r = sqrt(fmax(st * h.il2, 1e-30));
-  if (KID == K_M12) return exp(-r);
-  if (KID == K_M32) { double s = 1.7320508075688772 * r; return (s + 1.0) * exp(-s); }
+  if (KID == K_RBF) return exp_neg(0.5 * st * h.il2);
+  double r = sqrt_pos(fmin(fmax(st * h.il2, 1e-30), 1e300));
+  if (KID == K_M12) return exp_neg(r);
+  if (KID == K_M32) { double s = 1.7320508075688772 * r; return (s + 1.0) * exp_neg(s); }
   double s = 2.23606797749979 * r;
-  return (s + 1.0 + (5.0 / 3.0) * r * r) * exp(-s);
+  return (s + 1.0 + (5.0 / 3.0) * r * r) * exp_neg(s);
 }
 
 // value and d/d(lengthscale) (d/d(variance) for linear)
 template <int KID>
 __device__ __forceinline__ void kern_val_dl(double st, const Hyp& h, double& k, double& dk) {
   if (KID == K_LIN) { k = h.ls * st; dk = st; return; }
-  if (KID == K_RBF) { k = exp(-0.5 * st * h.il2); dk = k * st * h.il2 * h.il; return; }
-  double r = sqrt(fmax(st * h.il2, 1e-30));
-  if (KID == K_M12) { k = exp(-r); dk = k * r * h.il; return; }
+  if (KID == K_RBF) { k = exp_neg(0.5 * st * h.il2); dk = k * st * h.il2 * h.il; return; }
+  double r = sqrt_pos(fmin(fmax(st * h.il2, 1e-30), 1e300));
+  if (KID == K_M12) { k = exp_neg(r); dk = k * r * h.il; return; }
   if (KID == K_M32) {
-    double s = 1.7320508075688772 * r, e = exp(-s);
+    double s = 1.7320508075688772 * r, e = exp_neg(s);
     k = (s + 1.0) * e; dk = 3.0 * r * r * e * h.il; return;
   }
-  double s = 2.23606797749979 * r, e = exp(-s);
+  double s = 2.23606797749979 * r, e = exp_neg(s);
   k = (s + 1.0 + (5.0 / 3.0) * r * r) * e;
   dk = (5.0 / 3.0) * r * r * (1.0 + s) * e * h.il;
 }
