@@ -3,7 +3,7 @@ against the batched independent mode on one small Set14 x3 image.  usage: python
 import sys, time, numpy as np, torch
 sys.path.insert(0, ".")
 from PIL import Image
-from super_resolution_amd import kernels as K, ops
+from super_resolution_amd import kernels as K
 from super_resolution_amd.gprsr import GPRSR, ColorSpace
 i = int(sys.argv[1]) if len(sys.argv) > 1 else 6
 lr = np.array(Image.open(f"tests/golden/set14_x3/lr_{i:03d}.png"))
@@ -15,5 +15,3 @@ for mode in ("independent", "chain"):
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
     nfit = sum(int(f.numel()) for f in g.stats.flags)
     print(f"{mode:12s} image {i} {lr.shape}: {dt*1e3:8.1f} ms for {nfit} fits = {dt*1e3/nfit:6.2f} ms/fit", flush=True)
-if len(sys.argv) > 2:
-    ops.prof_enable(True) if hasattr(ops, "prof_enable") else None

@@ -113,6 +113,94 @@ int run14(double* out, const char* name) {
   return 0;
 }
 
+
+// 14 waves, block-balanced: waves land on SIMD (wave % 4) (checked by k_simd_probe), so SIMD0 holds 4 waves and must
+// get 13 of the 49 blocks (4+3+3+3), SIMDs 1..3 get 12 (3+3+3+3 / 4+4+4 / 4+4+4).  Strip s is shared by one
+// 4-block wave (column blocks 0-3) and one 3-block wave (4-6).
+__constant__ int c_strip[14] = {0, 0, 1, 2, 1, 2, 3, 4, 3, 4, 5, 6, 5, 6};
+__constant__ int c_wide[14]  = {1, 0, 1, 1, 0, 0, 1, 1, 0, 0, 1, 1, 0, 0};
+template <bool BARRIER>
+__global__ void __launch_bounds__(896, 7) k_loop14b(double* out, int chunks) {
+  __shared__ double lds[4 * KC * NB];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int e = tid; e < 4 * KC * NB; e += 896) lds[e] = 1e-3 * (e % 97);
+  __syncthreads();
+  const int strip = c_strip[wave], wide = c_wide[wave];
+  v4d acc[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int ch = 0; ch < chunks; ++ch) {
+    const double* As = lds + (ch & 1) * 2 * KC * NB;
+    const double* Bs = As + KC * NB;
+    if (BARRIER) __syncthreads();
+    if (wide) {
+#pragma unroll
+      for (int ks = 0; ks < KC / 4; ++ks) {
+        const int row = (ks * 4 + lk) * NB;
+        const double av = As[row + 16 * strip + lr];
+#pragma unroll
+        for (int t = 0; t < 4; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[row + 16 * t + lr], acc[t], 0, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < KC / 4; ++ks) {
+        const int row = (ks * 4 + lk) * NB;
+        const double av = As[row + 16 * strip + lr];
+#pragma unroll
+        for (int t = 0; t < 3; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[row + 16 * (4 + t) + lr], acc[t], 0, 0, 0);
+      }
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+  if (s == 12345.678) out[0] = s;
+}
+
+template <bool BARRIER>
+int run14b(double* out, const char* name) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int chunks = 700, grid = 256 * 2 * 8;
+  hipLaunchKernelGGL((k_loop14b<BARRIER>), dim3(grid), dim3(896), 0, 0, out, 7);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL((k_loop14b<BARRIER>), dim3(grid), dim3(896), 0, 0, out, chunks);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)grid * 49 * chunks * 4 * 2048.0;
+  printf("%-34s %.3f ms  %.1f TFLOP/s\n", name, ms, flops / ms * 1e-9);
+  return 0;
+}
+
+// which SIMD does wave w of a workgroup land on?  HW_ID (hwreg 4) bits [5:4] = SIMD_ID.
+__global__ void k_simd_probe(int* simd) {
+  const int wave = threadIdx.x >> 6;
+  const unsigned id = __builtin_amdgcn_s_getreg(4 | (4 << 6) | (1 << 11));
+  if ((threadIdx.x & 63) == 0) simd[blockIdx.x * (blockDim.x >> 6) + wave] = (int)id;
+}
+
+int probe(int waves) {
+  const int nblk = 1024;
+  int* d; CK(hipMalloc(&d, nblk * waves * sizeof(int)));
+  hipLaunchKernelGGL(k_simd_probe, dim3(nblk), dim3(64 * waves), 0, 0, d);
+  CK(hipDeviceSynchronize());
+  int* h = new int[nblk * waves];
+  CK(hipMemcpy(h, d, nblk * waves * sizeof(int), hipMemcpyDeviceToHost));
+  int hist[16][4] = {};
+  int rr = 0;
+  for (int b = 0; b < nblk; ++b) {
+    bool ok = true;
+    for (int w = 0; w < waves; ++w) { hist[w][h[b * waves + w] & 3]++; if (((h[b * waves + w] - h[b * waves]) & 3) != (w & 3)) ok = false; }
+    rr += ok;
+  }
+  printf("SIMD of wave w over %d workgroups of %d waves (round-robin from wave 0's SIMD in %d of them):\n", nblk, waves, rr);
+  for (int w = 0; w < waves; ++w) printf("  wave %2d: %4d %4d %4d %4d\n", w, hist[w][0], hist[w][1], hist[w][2], hist[w][3]);
+  delete[] h; CK(hipFree(d));
+  return 0;
+}
+
 int main() {
   double* out; CK(hipMalloc(&out, 8));
   run<7, true, 7>(out, "7 waves, barrier/chunk, 7 acc");
@@ -123,5 +211,9 @@ int main() {
   run<8, false, 7>(out, "8 waves, no barrier, 7 acc");
   run14<true>(out, "14 half-strip waves, barrier");
   run14<false>(out, "14 half-strip waves, no barrier");
+  run14b<true>(out, "14 waves block-balanced, barrier");
+  run14b<false>(out, "14 waves block-balanced, no barrier");
+  probe(7);
+  probe(14);
   return 0;
 }
