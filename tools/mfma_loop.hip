@@ -201,6 +201,71 @@ int probe(int waves) {
   return 0;
 }
 
+// Producer/consumer variant: 7 compute waves + 1 wave that would issue the DMA.  No s_barrier in the loop:
+// ready[buf] (set by the producer) and done[buf] (ds_add by each consumer) are LDS flags; a consumer never waits
+// for another consumer.  Spins are bounded (a stuck flag ends the loop instead of hanging the GPU).
+__global__ void __launch_bounds__(512, 4) k_loop_pc(double* out, int chunks) {
+  __shared__ double lds[4 * KC * NB];
+  __shared__ int ready[2], done[2];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int lr = lane & 15, lk = lane >> 4;
+  for (int e = tid; e < 4 * KC * NB; e += 512) lds[e] = 1e-3 * (e % 97);
+  if (tid < 2) { ready[tid] = 0; done[tid] = 0; }
+  __syncthreads();
+  volatile int* vready = ready;
+  volatile int* vdone = done;
+  v4d acc[7];
+#pragma unroll
+  for (int t = 0; t < 7; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  if (wave == 7) {
+    for (int ch = 0; ch < chunks; ++ch) {
+      const int b = ch & 1, need = 7 * (ch >> 1);
+      int spins = 0;
+      while (vdone[b] < need && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+      // (the DMA of chunk ch into buffer b and its s_waitcnt vmcnt(0) would go here)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) vready[b] = ch + 1;
+    }
+  } else {
+    for (int ch = 0; ch < chunks; ++ch) {
+      const int b = ch & 1;
+      int spins = 0;
+      while (vready[b] < ch + 1 && ++spins < (1 << 20)) __builtin_amdgcn_s_sleep(1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      const double* As = lds + b * 2 * KC * NB;
+      const double* Bs = As + KC * NB;
+#pragma unroll
+      for (int ks = 0; ks < KC / 4; ++ks) {
+        const int row = (ks * 4 + lk) * NB;
+        const double av = As[row + 16 * wave + lr];
+#pragma unroll
+        for (int t = 0; t < 7; ++t) acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, Bs[row + 16 * t + lr], acc[t], 0, 0, 0);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      if (lane == 0) atomicAdd(&done[b], 1);
+    }
+  }
+  double s = 0.0;
+#pragma unroll
+  for (int t = 0; t < 7; ++t) s += acc[t][0] + acc[t][1] + acc[t][2] + acc[t][3];
+  if (s == 12345.678) out[0] = s;
+}
+
+int run_pc(double* out, const char* name) {
+  hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+  const int chunks = 700, grid = 256 * 2 * 8;
+  hipLaunchKernelGGL(k_loop_pc, dim3(grid), dim3(512), 0, 0, out, 7);
+  CK(hipDeviceSynchronize());
+  CK(hipEventRecord(e0, 0));
+  hipLaunchKernelGGL(k_loop_pc, dim3(grid), dim3(512), 0, 0, out, chunks);
+  CK(hipEventRecord(e1, 0));
+  CK(hipEventSynchronize(e1));
+  float ms; CK(hipEventElapsedTime(&ms, e0, e1));
+  const double flops = (double)grid * 7 * chunks * 4 * 7 * 2048.0;
+  printf("%-34s %.3f ms  %.1f TFLOP/s\n", name, ms, flops / ms * 1e-9);
+  return 0;
+}
+
 int main() {
   double* out; CK(hipMalloc(&out, 8));
   run<7, true, 7>(out, "7 waves, barrier/chunk, 7 acc");
@@ -213,6 +278,7 @@ int main() {
   run14<false>(out, "14 half-strip waves, no barrier");
   run14b<true>(out, "14 waves block-balanced, barrier");
   run14b<false>(out, "14 waves block-balanced, no barrier");
+  run_pc(out, "7+1 waves, LDS flags, no barrier");
   probe(7);
   probe(14);
   return 0;
