@@ -8,7 +8,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libgpsr.so")
+LIB_PATH = os.environ.get("GPSR_LIB", os.path.join(_HERE, "libgpsr.so"))   # override: instrumented debug builds (tools/upd_trace.py)
 SRC = os.path.join(_HERE, "csrc", "gpsr_api.hip")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 HIPCC_FLAGS = ["-O3", "--offload-arch=gfx950", "-shared", "-fPIC", "-ffp-contract=off"]

@@ -795,3 +795,14 @@ extern "C" int gpsr_axpy(const double* a, const double* b, double alpha, double*
   CHECK_LAUNCH("k_axpy");
   return 0;
 }
+
+#ifdef GPSR_UPD_TRACE
+// debug build only (tools/upd_trace.py): read (and clear) the k_update2 cycle counters
+extern "C" int gpsr_debug_upd_trace(unsigned long long* out8) {
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_upd_trace), 8 * sizeof(unsigned long long));
+  if (e != hipSuccess) return hip_fail(e, "trace read");
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  e = hipMemcpyToSymbol(HIP_SYMBOL(g_upd_trace), z, sizeof(z));
+  return e == hipSuccess ? 0 : hip_fail(e, "trace clear");
+}
+#endif

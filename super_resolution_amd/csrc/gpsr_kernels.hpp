@@ -639,17 +639,22 @@ __device__ __forceinline__ void store_strip_transposed(const v4d acc[NBT], doubl
 __device__ __forceinline__ void dma_chunk(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop,
                                           int ldb, int chunk, double* __restrict__ bufA, double* __restrict__ bufB,
                                           int wave, int lane) {
-  // 14 KiB per operand = 14 wave-instructions of 1 KiB; wave w issues pieces 2w and 2w+1
+  // 14 KiB per operand = 14 wave-instructions of 1 KiB; wave w issues pieces 2w and 2w+1.
+  // Address = wave-uniform chunk base (scalar registers) + a 32-bit per-lane byte offset that does not depend on
+  // the chunk: the compiler keeps the four offsets in registers for the whole tile and the per-chunk address
+  // arithmetic is scalar (measured with GPSR_UPD_TRACE=3: the 64-bit vector multiplies of the naive form cost
+  // ~500 cycles per chunk between the barrier and the first MFMA).
+  const char* pa = (const char*)(Aop + (size_t)(chunk * KC) * lda);
+  const char* pb = (const char*)(Bop + (size_t)(chunk * KC) * ldb);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int piece = 2 * wave + u;
     const int e = piece * 128 + lane * 2;
     const int kk = e / NB, c = e % NB;
-    const double* ga = Aop + (size_t)(chunk * KC + kk) * lda + c;
-    const double* gb = Bop + (size_t)(chunk * KC + kk) * ldb + c;
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+    const unsigned oa = (unsigned)(kk * lda + c) * 8u, ob = (unsigned)(kk * ldb + c) * 8u;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + oa),
                                      (__attribute__((address_space(3))) void*)(bufA + piece * 128), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + ob),
                                      (__attribute__((address_space(3))) void*)(bufB + piece * 128), 16, 0, 0);
   }
 }
@@ -779,6 +784,15 @@ __device__ __forceinline__ void grad1_partials(const v4d acc[NBT], bool diag, co
   }
 }
 
+#ifdef GPSR_UPD_TRACE
+// Debug build only (tools/upd_trace.py): where the cycles of a k_update2 compute wave go.  Sums over all
+// wave-tiles: [0] wave-tiles, [1] cycles kernel entry -> exit, [2] waiting for this wave's DMA (s_waitcnt vmcnt),
+// [3] waiting at the chunk barrier, [4] issuing the next chunk's DMA, [5] the chunk's LDS reads + MFMAs,
+// [6] kernel entry -> first chunk wait, [7] last MFMA issued -> kernel exit (C stores, mirror).
+__device__ unsigned long long g_upd_trace[8];
+#define TRC_CLK() __builtin_readcyclecounter()
+#endif
+
 // Two-phase product for the fused update of TWO pivot steps: acc += (+-)A1 B1 + (+-)A2 B2 with one
 // pass over C (k-depth 224), the 14 chunks double-buffered as one continuous stream.  LATEC as in
 // tile_product_dma_latec (C read overlapped with chunk 0, which runs on zeroed accumulators).
@@ -799,10 +813,16 @@ __device__ __forceinline__ void tile_product_dma2(const double* __restrict__ A1,
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
   }
+#ifdef GPSR_UPD_TRACE
+  unsigned long long trc = 0;   // GPSR_UPD_TRACE == 1: s_waitcnt + barrier; == 2: LDS reads + MFMAs; == 3: DMA issue
+#endif
 #pragma unroll
   for (int g = 0; g < 2 * NC; ++g) {
     double* cur = lds + (g & 1) * 2 * DMA_CHUNK;
     double* nxt = lds + ((g + 1) & 1) * 2 * DMA_CHUNK;
+#if GPSR_UPD_TRACE == 1
+    const unsigned long long ta = TRC_CLK();
+#endif
     if (LATEC && g == 0) {
       asm volatile("s_waitcnt vmcnt(28)" ::: "memory");   // chunk 0's DMA pieces are older than the 28 C loads
       __builtin_amdgcn_s_barrier();
@@ -810,15 +830,33 @@ __device__ __forceinline__ void tile_product_dma2(const double* __restrict__ A1,
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
     }
+#if GPSR_UPD_TRACE == 1
+    trc += TRC_CLK() - ta;
+#endif
+#if GPSR_UPD_TRACE == 3
+    const unsigned long long tb = TRC_CLK();
+#endif
     if (g + 1 < NC) dma_chunk(A1, lda1, B1, ldb1, g + 1, nxt, nxt + DMA_CHUNK, wave, lane);
     else if (g + 1 < 2 * NC) dma_chunk(A2, lda2, B2, ldb2, g + 1 - NC, nxt, nxt + DMA_CHUNK, wave, lane);
+#if GPSR_UPD_TRACE == 3
+    trc += TRC_CLK() - tb;
+#endif
+#if GPSR_UPD_TRACE == 2
+    const unsigned long long tc = TRC_CLK();
+#endif
     if (g < NC) chunk_mfma_dma<SKIP1, NEG1>(cur, cur + DMA_CHUNK, acc, wave, lane, g);
     else chunk_mfma_dma<SKIP2, NEG2>(cur, cur + DMA_CHUNK, acc, wave, lane, g - NC);
     if (LATEC && g == 0) {
 #pragma unroll
       for (int t = 0; t < NBT; ++t) acc[t] += c0[t];
     }
+#if GPSR_UPD_TRACE == 2
+    trc += TRC_CLK() - tc;
+#endif
   }
+#ifdef GPSR_UPD_TRACE
+  if (LATEC && lane == 0) atomicAdd(&g_upd_trace[1 + GPSR_UPD_TRACE], trc);   // off-diagonal trailing tiles only
+#endif
 }
 
 template <bool G1>   // G1: last pivot step of a fit evaluation, leaves the alpha mat-vec partials (own instantiation:
@@ -922,6 +960,9 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
           int total) {
   __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
   const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+#ifdef GPSR_UPD_TRACE
+  const unsigned long long trc_t0 = TRC_CLK();
+#endif
   const int lr = lane & 15, lk = lane >> 4;
   const int v = xcd_remap(blockIdx.x, total);
   const int k2 = k1 + 1, nb2 = nblk - 2, ntri2 = nb2 * (nb2 + 1) / 2;
@@ -952,12 +993,28 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
       __syncthreads();
       store_strip_transposed(acc, Ab + (size_t)(I * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr, wave);
     } else {
+#ifdef GPSR_UPD_TRACE
+      const unsigned long long trc_t1 = TRC_CLK();
+#endif
       tile_product_dma2<SKIP_NONE, true, SKIP_NONE, true, true>(W1 + I * NB, N, W1 + J * NB, N, W2 + I * NB, N,
                                                                 W2 + J * NB, N, lds, acc, Ct, (size_t)N, wave, lane);
+#ifdef GPSR_UPD_TRACE
+      const unsigned long long trc_t2 = TRC_CLK();
+#endif
 #pragma unroll
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+#ifdef GPSR_UPD_TRACE
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores retired: what the workgroup slot really costs
+      const unsigned long long trc_t3 = TRC_CLK();
+      if (lane == 0) {
+        atomicAdd(&g_upd_trace[0], 1ull);
+        atomicAdd(&g_upd_trace[1], trc_t3 - trc_t0);
+        atomicAdd(&g_upd_trace[6], trc_t1 - trc_t0);
+        atomicAdd(&g_upd_trace[7], trc_t3 - trc_t2);
+      }
+#endif
     }
   } else if (t0 < ntri2 + nb2) {                      // (b)
     int I = t0 - ntri2; if (I >= k1) I += 2;
