@@ -1081,21 +1081,24 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
 __device__ __forceinline__ void dma_chunk_panel(const double* __restrict__ Tsrc, size_t N, bool below,
                                                 const double* __restrict__ U, int chunk, double* __restrict__ bufA,
                                                 double* __restrict__ bufB, int wave, int lane) {
+  // wave-uniform chunk bases + chunk-independent 32-bit per-lane byte offsets (see dma_chunk)
+  const char* pb = (const char*)(U + (size_t)(chunk * KC) * NB);
+  const char* pa = (const char*)(below ? Tsrc + chunk * KC : Tsrc + (size_t)(chunk * KC) * N);
 #pragma unroll
   for (int u = 0; u < 2; ++u) {
     const int piece = 2 * wave + u;
     const int e = piece * 128 + lane * 2;
     const int kk = e / NB, c = e % NB;
-    const double* gb = U + (size_t)(chunk * KC + kk) * NB + c;
-    const double* ga;
-    if (!below) ga = Tsrc + (size_t)(chunk * KC + kk) * N + c;
+    const unsigned ob = (unsigned)(kk * NB + c) * 8u;
+    unsigned oa;
+    if (!below) oa = (unsigned)(kk * (int)N + c) * 8u;
     else {
       const int slot = piece * 64 + lane, r = slot >> 3, j = slot & 7;
-      ga = Tsrc + (size_t)r * N + chunk * KC + 2 * (j ^ ((r >> 1) & 7));
+      oa = (unsigned)(r * (int)N + 2 * (j ^ ((r >> 1) & 7))) * 8u;
     }
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)ga,
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pa + oa),
                                      (__attribute__((address_space(3))) void*)(bufA + piece * 128), 16, 0, 0);
-    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)gb,
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + ob),
                                      (__attribute__((address_space(3))) void*)(bufB + piece * 128), 16, 0, 0);
   }
 }
