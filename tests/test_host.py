@@ -39,10 +39,31 @@ def test_library_exports_every_declared_symbol():
 
 def test_library_is_gfx950_code_object():
     from super_resolution_amd import _lib
+    import glob
+    before = set(glob.glob(_lib.LIB_PATH + ".*"))
     out = subprocess.run(["/opt/rocm/lib/llvm/bin/llvm-objdump", "--offloading", _lib.LIB_PATH],
                          capture_output=True, text=True)
+    for f in set(glob.glob(_lib.LIB_PATH + ".*")) - before:   # llvm-objdump leaves the unbundled code objects beside the input
+        os.remove(f)
     if out.returncode == 0:
         assert "gfx950" in out.stdout
+
+
+def test_empty_batches_are_no_ops():
+    """B = 0 (an image rank with no patches in its shard, an empty job list) returns 0 from every batched entry
+    point before anything is dereferenced or launched -- so this runs without a GPU."""
+    from super_resolution_amd import _lib
+    lib = _lib.load()
+    N = None
+    assert lib.gpsr_gather(N, N, N, 64, 64, 2, 20, N, 0, N, 18, N, N, N, N) == 0
+    assert lib.gpsr_init_hypers(N, 0, 324, 3, 0.0, 0.0, N, N, N) == 0
+    assert lib.gpsr_covariance(N, 0, 324, 8, 3, N, N, N) == 0
+    assert lib.gpsr_covariance_grad(N, 0, 324, 8, 3, N, N, N, N) == 0
+    assert lib.gpsr_invert(N, 0, 336, N, N, N, 0, N) == 0
+    assert lib.gpsr_fit(N, N, 0, 324, 8, 3, N, 50, 0.1, N, N, N, N, 0, N) == 0
+    assert lib.gpsr_loss_grad(N, N, 0, 324, 8, 3, N, N, N, N, N, 0, N) == 0
+    assert lib.gpsr_predict(N, N, N, N, 0, 324, 1444, 3, N, N) == 0
+    assert lib.gpsr_invert_workspace_bytes(0, 336) == 0
 
 
 def test_ops_refuse_cpu_tensors():
