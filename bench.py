@@ -148,7 +148,7 @@ def main():
     imgs_u8, s = workload(a.workload, world if a.scaling == "weak" else 1)
     out_px = sum(im.shape[0] * s * im.shape[1] * s for im in imgs_u8)
     n_patches = sum(patch_count(im.shape, s) for im in imgs_u8)
-    g = GPRSR(s, kern, ColorSpace.GRAYSCALE, shard=(rank, world) if world > 1 else None,
+    g = GPRSR(s, kern, ColorSpace.GRAYSCALE, warm_start="independent", shard=(rank, world) if world > 1 else None,
               max_workspace_bytes=int(a.max_workspace_gb * (1 << 30)))
     imgs = [ops.u8_to_unit(torch.as_tensor(im).to(dev)) for im in imgs_u8]
 

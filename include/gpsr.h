@@ -54,9 +54,12 @@ const char* gpsr_version(void);
 const char* gpsr_last_error(void);
 
 /*
- * Opaque context = a device and one workspace allocation sized for gpsr_fit /
- * gpsr_predict_pixels of up to max_B GPs of up to max_n training points (d = 8 features),
- * for callers that do not bring their own allocator.  gpsr_create makes
+ * Opaque context = a device and one workspace allocation, for callers that do not bring
+ * their own allocator.  It is sized for gpsr_fit / gpsr_loss_grad /
+ * gpsr_invert of up to max_B GPs of up to max_n training points (d <= 64 features) and,
+ * when max_m > 0, also for gpsr_predict_pixels of up to max_B patches (any chunk) with
+ * n <= max_n training and m <= max_m test points per patch (m = (p*s-2)^2); max_m = 0
+ * leaves gpsr_predict_pixels out (it would answer "workspace too small").  gpsr_create makes
  * device_id current and is the only allocating call of the library (one hipMalloc);
  * gpsr_destroy frees it.  Pass gpsr_ctx_workspace() / gpsr_ctx_workspace_bytes() as the
  * `workspace` arguments below.  One context per (device, stream): calls that share a
@@ -64,7 +67,7 @@ const char* gpsr_last_error(void);
  * No counterpart in the reference (GPyTorch allocates through torch).
  */
 typedef struct gpsr_ctx gpsr_ctx;
-gpsr_ctx* gpsr_create(int device_id, int max_B, int max_n);
+gpsr_ctx* gpsr_create(int device_id, int max_B, int max_n, int max_m);
 void gpsr_destroy(gpsr_ctx* ctx);
 void* gpsr_ctx_workspace(const gpsr_ctx* ctx);
 size_t gpsr_ctx_workspace_bytes(const gpsr_ctx* ctx);
@@ -95,12 +98,15 @@ int gpsr_gather(const double* train_in, const double* train_tgt, const double* t
 /*
  * Per-patch initial hyper-parameters, gprsr.py:162-174: noise=1e-3,
  * constant=mean(y.float()); RBF: lengthscale=.223, outputscale=var(y.float());
- * other kernels: raw_outputscale/raw_lengthscale = init_os_ls[0..1], or, when
- * carry != NULL, the two floats at carry[2], carry[3] (device pointer to a
- * previous GP's raw[4] -- the reference's warm-start chain).
+ * other kernels: raw_outputscale/raw_lengthscale = init_raw_os/init_raw_ls, or, when
+ * carry != NULL, the two floats at carry[b*carry_stride + 2], carry[b*carry_stride + 3]
+ * (device pointer to previous GPs' raw[4] rows -- the reference's warm-start chain through
+ * the kernel singletons, kernels.py:7-13 / SURVEY.md F5).  carry_stride 0: every GP of the
+ * call continues the same chain link; carry_stride >= 4: GP b continues the chain whose last
+ * raw row is carry + b*carry_stride (B chains stepped at once, one GP each).
  */
 int gpsr_init_hypers(const double* y, int B, int n, int kernel_id,
-                     float init_raw_os, float init_raw_ls, const float* carry,
+                     float init_raw_os, float init_raw_ls, const float* carry, int carry_stride,
                      float* raw, void* stream);
 
 /*
@@ -250,6 +256,38 @@ int gpsr_sepfilter_sym(const double* src, int H, int W, double* dst, const doubl
                        void* stream);
 int gpsr_filter3x3(const double* src, int H, int W, double* dst, const double* kern, void* stream);
 int gpsr_axpy(const double* a, const double* b, double alpha, double* dst, size_t n, void* stream);
+
+/*
+ * uint8 colour stages, so that a colour image goes to the GPU once.  OpenCV's
+ * fixed-point paths restated in integer arithmetic (bit-exact by construction):
+ *   gpsr_bgr2gray    cv.cvtColor(COLOR_BGR2GRAY): 15-bit table 3735/19235/9798     gprsr.py:53, evaluation.py:96
+ *   gpsr_bgr2yuv     cv.cvtColor(COLOR_BGR2YUV)  + cv.split -> planes Y, U, V      gprsr.py:57-58
+ *   gpsr_yuv2bgr     cv.merge + cv.cvtColor(COLOR_YUV2BGR)                         gprsr.py:62-63
+ *   gpsr_bgr2ycrcb / gpsr_ycrcb2bgr   the same for YCrCb                           agpr.py:150-156
+ *   gpsr_resample_u8 cv.resize(INTER_CUBIC) on a uint8 plane: 11-bit fixed-point taps (xa, ya = cvRound(coef*2048),
+ *                    host tables [n][4] as for gpsr_resample), (x + 2^21) >> 22, saturated      gprsr.py:60-61, agpr.py:152-153
+ * bgr: [npx][3] interleaved (cv.imread layout); planes: [npx].
+ */
+int gpsr_bgr2gray(const uint8_t* bgr, uint8_t* gray, size_t npx, void* stream);
+int gpsr_bgr2yuv(const uint8_t* bgr, uint8_t* Y, uint8_t* U, uint8_t* V, size_t npx, void* stream);
+int gpsr_yuv2bgr(const uint8_t* Y, const uint8_t* U, const uint8_t* V, uint8_t* bgr, size_t npx, void* stream);
+int gpsr_bgr2ycrcb(const uint8_t* bgr, uint8_t* Y, uint8_t* Cr, uint8_t* Cb, size_t npx, void* stream);
+int gpsr_ycrcb2bgr(const uint8_t* Y, const uint8_t* Cr, const uint8_t* Cb, uint8_t* bgr, size_t npx, void* stream);
+int gpsr_resample_u8(const uint8_t* src, int Hs, int Ws, uint8_t* dst, int Hd, int Wd,
+                     const int32_t* xi, const int32_t* xa, const int32_t* yi, const int32_t* ya, void* stream);
+
+/*
+ * Evaluator metrics (evaluation.py:83-98): two uint8 grey images [H][W], cropped by `crop`
+ * px per side (preprocess_image, evaluation.py:95-98), skimage's definitions restated:
+ *   out[0] = peak_signal_noise_ratio(data_range=255) in dB (+inf when identical)   evaluation.py:87
+ *   out[1] = structural_similarity(data_range=255): 7x7 uniform window, sample covariance, K1 .01, K2 .03,
+ *            mean over the windows inside the image                                evaluation.py:93
+ *   out[2] = mean squared error
+ * out: device double[3].  Deterministic (integer window sums, fixed-order reductions).
+ */
+size_t gpsr_metrics_workspace_bytes(int H, int W, int crop);
+int gpsr_metrics(const uint8_t* a, const uint8_t* b, int H, int W, int crop, double* out,
+                 void* workspace, size_t workspace_bytes, void* stream);
 
 /*
  * Kernel timing for bench.py's roofline line: HIP-event brackets around the

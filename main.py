@@ -28,8 +28,12 @@ def parse_args(argv=None):
     ap.add_argument("--stride-percentage", type=float, default=0.9, help="STRIDE_PERCENTAGE")
     ap.add_argument("--patch-interpolation", default="average", choices=["average", "bilinear"],
                     help="PATCH_INTERPOLATION")
-    ap.add_argument("--warm-start", default="independent", choices=["independent", "chain"],
-                    help="independent: batched engine; chain: the reference's serial warm start across patches")
+    ap.add_argument("--warm-start", default="chain", choices=["chain", "chain_per_image", "independent"],
+                    help="chain (default): the reference's semantics -- its kernel objects are singletons, so every patch "
+                         "starts Adam from the previous patch's optimum, across patches, phases and images (serial); "
+                         "chain_per_image: every image as the first image of a fresh reference process (images run "
+                         "concurrently); independent: every patch from the initial values -- the batched, patch-sharded "
+                         "engine, a different algorithm at pixel level for non-RBF kernels")
     ap.add_argument("--batch-images", action="store_true", help="fit the patches of all images in one GP batch")
     ap.add_argument("--dataset-dir", default="Set14", help="folder holding image_SRF_<s>/img_XXX_SRF_<s>_LR.png")
     ap.add_argument("--evaluate", action="store_true", help="print PSNR/SSIM against *_HR.png (evaluation.py)")
@@ -80,7 +84,7 @@ def main(argv=None):
     name = kernels.get_kernel_name(kern)
     gray = cs == gprsr.ColorSpace.GRAYSCALE
     paths = [(i, f"{a.dataset_dir}/image_SRF_{a.srf}/img_{i:03d}_SRF_{a.srf}_LR.png") for i in nums]
-    if a.batch_images and gray and a.warm_start == "independent":
+    if a.batch_images and gray and a.warm_start != "chain":
         t0 = time.time()
         outs = g.apply_for_channel_batch([imgproc.bgr2gray(imread_bgr(p)) for _, p in paths])
         if gprsr.DO_TIMING:

@@ -22,13 +22,13 @@ SIGNATURES = {
     "gpsr_version": (ctypes.c_char_p, []),
     "gpsr_last_error": (ctypes.c_char_p, []),
     "gpsr_padded_n": (c_int, [c_int]),
-    "gpsr_create": (c_void_p, [c_int, c_int, c_int]),
+    "gpsr_create": (c_void_p, [c_int, c_int, c_int, c_int]),
     "gpsr_destroy": (None, [c_void_p]),
     "gpsr_ctx_workspace": (c_void_p, [c_void_p]),
     "gpsr_ctx_workspace_bytes": (c_size_t, [c_void_p]),
     "gpsr_flag_count": (c_int, [c_void_p, c_int, c_void_p]),
     "gpsr_gather": (c_int, [c_void_p] * 3 + [c_int] * 4 + [c_void_p, c_int, c_void_p, c_int] + [c_void_p] * 4),
-    "gpsr_init_hypers": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_void_p, c_void_p]),
+    "gpsr_init_hypers": (c_int, [c_void_p, c_int, c_int, c_int, c_float, c_float, c_void_p, c_int, c_void_p, c_void_p]),
     "gpsr_covariance": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gpsr_covariance_grad": (c_int, [c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gpsr_invert_workspace_bytes": (c_size_t, [c_int, c_int]),
@@ -58,6 +58,14 @@ SIGNATURES = {
     "gpsr_sepfilter_sym": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "gpsr_filter3x3": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_void_p]),
     "gpsr_axpy": (c_int, [c_void_p, c_void_p, ctypes.c_double, c_void_p, c_size_t, c_void_p]),
+    "gpsr_bgr2gray": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gpsr_bgr2yuv": (c_int, [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "gpsr_yuv2bgr": (c_int, [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "gpsr_bgr2ycrcb": (c_int, [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "gpsr_ycrcb2bgr": (c_int, [c_void_p] * 4 + [c_size_t, c_void_p]),
+    "gpsr_resample_u8": (c_int, [c_void_p, c_int, c_int, c_void_p, c_int, c_int] + [c_void_p] * 5),
+    "gpsr_metrics_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
+    "gpsr_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
 }
 
 

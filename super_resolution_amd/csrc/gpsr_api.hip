@@ -101,14 +101,15 @@ extern "C" int gpsr_gather(const double* train_in, const double* train_tgt, cons
 static float inv_softplus_host(float x) { return x + logf(-expm1f(-x)); }
 
 extern "C" int gpsr_init_hypers(const double* y, int B, int n, int kernel_id, float init_raw_os,
-                                float init_raw_ls, const float* carry, float* raw, void* stream) {
+                                float init_raw_ls, const float* carry, int carry_stride, float* raw, void* stream) {
   if (B <= 0) return 0;
   if (!y || !raw || n < 2) return arg_fail("init_hypers");
+  if (carry && carry_stride != 0 && carry_stride < 4) return arg_fail("carry_stride (0: one carry for all GPs, >= 4: floats between rows)");
   if (kernel_id < 0 || kernel_id > 4) return arg_fail("kernel_id");
   const float raw_noise0 = inv_softplus_host(0.001f - 1e-4f);
   const float raw_ls_rbf = inv_softplus_host(0.223f);
   hipLaunchKernelGGL(k_init_hypers, dim3(B), dim3(256), 0, (hipStream_t)stream, y, n, kernel_id, raw_noise0,
-                     raw_ls_rbf, init_raw_os, init_raw_ls, carry, raw);
+                     raw_ls_rbf, init_raw_os, init_raw_ls, carry, carry_stride, raw);
   CHECK_LAUNCH("k_init_hypers");
   return 0;
 }
@@ -570,11 +571,18 @@ extern "C" int gpsr_loss_grad(const double* X, const double* y, int B, int n, in
 // ---------------------------------------------------------------- context + flag count
 struct gpsr_ctx { int device; void* ws; size_t bytes; };
 
-extern "C" gpsr_ctx* gpsr_create(int device_id, int max_B, int max_n) {
-  if (max_B < 1 || max_n < 2 || gpsr_padded_n(max_n) > 16 * NB) { arg_fail("gpsr_create sizes"); return nullptr; }
+static size_t pix_ws_carve(char* base, int B, int Bc, int n, int m, struct PixWs* w);
+
+extern "C" gpsr_ctx* gpsr_create(int device_id, int max_B, int max_n, int max_m) {
+  if (max_B < 1 || max_n < 2 || max_m < 0 || gpsr_padded_n(max_n) > 16 * NB) { arg_fail("gpsr_create sizes"); return nullptr; }
   hipError_t e = hipSetDevice(device_id);
   if (e != hipSuccess) { hip_fail(e, "hipSetDevice"); return nullptr; }
-  gpsr_ctx* c = new gpsr_ctx{device_id, nullptr, gpsr_fit_workspace_bytes(max_B, max_n, 8)};
+  size_t bytes = gpsr_fit_workspace_bytes(max_B, max_n, 8);
+  if (max_m > 0) {   // gpsr_predict_pixels: locs, raw, pred, X, y, Xs, alpha on top of the fit workspace (chunk = all patches)
+    const size_t pix = pix_ws_carve(nullptr, max_B, max_B, max_n, max_m, nullptr);
+    if (pix > bytes) bytes = pix;
+  }
+  gpsr_ctx* c = new gpsr_ctx{device_id, nullptr, bytes};
   e = hipMalloc(&c->ws, c->bytes);
   if (e != hipSuccess) { hip_fail(e, "hipMalloc(workspace)"); delete c; return nullptr; }
   return c;
@@ -699,7 +707,7 @@ extern "C" int gpsr_predict_pixels(const double* train_in, const double* train_t
     const int bn = (B - b0 < Bc) ? B - b0 : Bc;
     int rc = gpsr_gather(train_in, train_tgt, test_in, H, W, s, p, w.locs + 2 * b0, bn, tidx, nt, w.X, w.y, w.Xs, stream);
     if (rc) return rc;
-    rc = gpsr_init_hypers(w.y, bn, n, kernel_id, init_raw_os, init_raw_ls, nullptr, raw + 4 * b0, stream);
+    rc = gpsr_init_hypers(w.y, bn, n, kernel_id, init_raw_os, init_raw_ls, nullptr, 0, raw + 4 * b0, stream);
     if (rc) return rc;
     rc = gpsr_fit(w.X, w.y, bn, n, 8, kernel_id, raw + 4 * b0, iters, lr, w.alpha, nullptr, flags + b0, w.fit,
                   fit_bytes, stream);
@@ -793,6 +801,81 @@ extern "C" int gpsr_axpy(const double* a, const double* b, double alpha, double*
   if (n == 0) return 0;
   hipLaunchKernelGGL(k_axpy, GRID1D(n), a, b, alpha, dst, n);
   CHECK_LAUNCH("k_axpy");
+  return 0;
+}
+
+// ---------------------------------------------------------------- uint8 colour stages + metrics
+extern "C" int gpsr_bgr2gray(const uint8_t* bgr, uint8_t* gray, size_t npx, void* stream) {
+  if (!bgr || !gray) return arg_fail("null pointer");
+  if (npx == 0) return 0;
+  hipLaunchKernelGGL(k_bgr2gray, GRID1D(npx), bgr, gray, npx);
+  CHECK_LAUNCH("k_bgr2gray");
+  return 0;
+}
+
+static int launch_bgr2ycc(const uint8_t* bgr, uint8_t* Y, uint8_t* CR, uint8_t* CB, size_t npx, int c_r, int c_b,
+                          void* stream) {
+  if (!bgr || !Y || !CR || !CB) return arg_fail("null pointer");
+  if (npx == 0) return 0;
+  hipLaunchKernelGGL(k_bgr2ycc, GRID1D(npx), bgr, Y, CR, CB, npx, c_r, c_b);
+  CHECK_LAUNCH("k_bgr2ycc");
+  return 0;
+}
+static int launch_ycc2bgr(const uint8_t* Y, const uint8_t* CR, const uint8_t* CB, uint8_t* bgr, size_t npx, int c0,
+                          int c1, int c2, int c3, void* stream) {
+  if (!bgr || !Y || !CR || !CB) return arg_fail("null pointer");
+  if (npx == 0) return 0;
+  hipLaunchKernelGGL(k_ycc2bgr, GRID1D(npx), Y, CR, CB, bgr, npx, c0, c1, c2, c3);
+  CHECK_LAUNCH("k_ycc2bgr");
+  return 0;
+}
+extern "C" int gpsr_bgr2yuv(const uint8_t* bgr, uint8_t* Y, uint8_t* U, uint8_t* V, size_t npx, void* stream) {
+  return launch_bgr2ycc(bgr, Y, V, U, npx, 14369, 8061, stream);       // V = .877 (R-Y), U = .492 (B-Y)
+}
+extern "C" int gpsr_yuv2bgr(const uint8_t* Y, const uint8_t* U, const uint8_t* V, uint8_t* bgr, size_t npx, void* stream) {
+  return launch_ycc2bgr(Y, V, U, bgr, npx, 18678, -9519, -6472, 33292, stream);
+}
+extern "C" int gpsr_bgr2ycrcb(const uint8_t* bgr, uint8_t* Y, uint8_t* Cr, uint8_t* Cb, size_t npx, void* stream) {
+  return launch_bgr2ycc(bgr, Y, Cr, Cb, npx, 11682, 9241, stream);
+}
+extern "C" int gpsr_ycrcb2bgr(const uint8_t* Y, const uint8_t* Cr, const uint8_t* Cb, uint8_t* bgr, size_t npx, void* stream) {
+  return launch_ycc2bgr(Y, Cr, Cb, bgr, npx, 22987, -11698, -5636, 29049, stream);
+}
+
+extern "C" int gpsr_resample_u8(const uint8_t* src, int Hs, int Ws, uint8_t* dst, int Hd, int Wd, const int32_t* xi,
+                                const int32_t* xa, const int32_t* yi, const int32_t* ya, void* stream) {
+  if (!src || !dst || !xi || !xa || !yi || !ya) return arg_fail("null pointer");
+  if (Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1) return arg_fail("resample_u8 shape");
+  hipLaunchKernelGGL(k_resample_u8, GRID1D((size_t)Hd * Wd), src, Ws, dst, Hd, Wd, xi, xa, yi, ya);
+  CHECK_LAUNCH("k_resample_u8");
+  return 0;
+}
+
+static size_t metrics_parts(int H, int W, int crop) {
+  const size_t Hc = (size_t)(H - 2 * crop), Wc = (size_t)(W - 2 * crop);
+  return (Hc * Wc + MET_THREADS - 1) / MET_THREADS;
+}
+extern "C" size_t gpsr_metrics_workspace_bytes(int H, int W, int crop) {
+  if (crop < 0 || H - 2 * crop < 1 || W - 2 * crop < 1) return 0;
+  return 2 * align256(metrics_parts(H, W, crop) * 8);
+}
+extern "C" int gpsr_metrics(const uint8_t* a, const uint8_t* b, int H, int W, int crop, double* out, void* workspace,
+                            size_t workspace_bytes, void* stream) {
+  if (!a || !b || !out || !workspace) return arg_fail("null pointer");
+  if (crop < 0 || H - 2 * crop < 1 || W - 2 * crop < 1) return arg_fail("metrics: image smaller than the crop");
+  if (workspace_bytes < gpsr_metrics_workspace_bytes(H, W, crop)) return arg_fail("workspace too small");
+  const int Hc = H - 2 * crop, Wc = W - 2 * crop;
+  const size_t parts = metrics_parts(H, W, crop);
+  if (parts > 0x7fffffff) return arg_fail("metrics: image too large");
+  unsigned long long* sse = (unsigned long long*)workspace;
+  double* ssp = (double*)((char*)workspace + align256(parts * 8));
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_metrics_partial, dim3((unsigned)parts), dim3(MET_THREADS), 0, st, a, b, W, crop, Hc, Wc, sse, ssp);
+  CHECK_LAUNCH("k_metrics_partial");
+  const double nwin = (Hc >= 7 && Wc >= 7) ? (double)(Hc - 6) * (double)(Wc - 6) : 0.0;
+  hipLaunchKernelGGL(k_metrics_final, dim3(1), dim3(MET_THREADS), 0, st, sse, ssp, (int)parts, (double)Hc * (double)Wc,
+                     nwin, out);
+  CHECK_LAUNCH("k_metrics_final");
   return 0;
 }
 

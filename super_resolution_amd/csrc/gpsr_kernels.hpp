@@ -190,7 +190,7 @@ __global__ void k_gather(const double* __restrict__ tin, const double* __restric
 // ------------------------------------------------------- initial hypers
 __global__ void k_init_hypers(const double* __restrict__ y, int n, int kid, float raw_noise0,
                               float raw_ls_rbf, float init_os, float init_ls,
-                              const float* __restrict__ carry, float* __restrict__ raw) {
+                              const float* __restrict__ carry, int carry_stride, float* __restrict__ raw) {
   __shared__ double red[256];
   const int b = blockIdx.x, tid = threadIdx.x;
   const double* yb = y + (size_t)b * n;
@@ -213,7 +213,7 @@ __global__ void k_init_hypers(const double* __restrict__ y, int n, int kid, floa
       r[2] = var + logf(-expm1f(-var));  // inv_softplus
       r[3] = raw_ls_rbf;
     } else if (carry) {
-      r[2] = carry[2]; r[3] = carry[3];
+      r[2] = carry[(size_t)b * carry_stride + 2]; r[3] = carry[(size_t)b * carry_stride + 3];
     } else {
       r[2] = init_os; r[3] = init_ls;
     }
@@ -1687,4 +1687,132 @@ __global__ void k_axpy(const double* __restrict__ a, const double* __restrict__ 
                        double* __restrict__ dst, size_t n) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) dst[i] = __dadd_rn(a[i], __dmul_rn(b[i], alpha));
+}
+
+// ------------------------------------------------ uint8 colour stages (cv.cvtColor / cv.resize on CV_8U, restated)
+// OpenCV's fixed-point paths: RGB2Gray<uchar> uses the 15-bit table (BY15 3735, GY15 19235, RY15 9798, >> 15);
+// RGB2YCrCb_i / YCrCb2RGB_i use the 14-bit yuv_shift constants.  Integer arithmetic: bit-exact by construction.
+__device__ __forceinline__ int descale_i(int x, int n) { return (x + (1 << (n - 1))) >> n; }
+__device__ __forceinline__ uint8_t sat_u8(int x) { return (uint8_t)(x < 0 ? 0 : (x > 255 ? 255 : x)); }
+
+// gprsr.py:53 / evaluation.py:96: BGR interleaved -> grey
+__global__ void k_bgr2gray(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ gray, size_t npx) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npx) return;
+  const int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+  gray[i] = (uint8_t)descale_i(b * 3735 + g * 19235 + r * 9798, 15);
+}
+
+// gprsr.py:57-58 (COLOR_BGR2YUV: c_r = 14369 (V), c_b = 8061 (U)) and agpr.py:150 (COLOR_BGR2YCrCb: 11682, 9241):
+// BGR interleaved -> three planes Y, Cr-like (from R-Y), Cb-like (from B-Y)
+__global__ void k_bgr2ycc(const uint8_t* __restrict__ bgr, uint8_t* __restrict__ Y, uint8_t* __restrict__ CR,
+                          uint8_t* __restrict__ CB, size_t npx, int c_r, int c_b) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npx) return;
+  const int b = bgr[3 * i], g = bgr[3 * i + 1], r = bgr[3 * i + 2];
+  const int y = descale_i(b * 1868 + g * 9617 + r * 4899, 14);
+  const int half = 128 << 14;
+  Y[i] = sat_u8(y);
+  CR[i] = sat_u8(descale_i((r - y) * c_r + half, 14));
+  CB[i] = sat_u8(descale_i((b - y) * c_b + half, 14));
+}
+
+// gprsr.py:62-63 (COLOR_YUV2BGR: 18678, -9519, -6472, 33292) and agpr.py:155-156 (COLOR_YCrCb2BGR: 22987, -11698,
+// -5636, 29049): planes -> BGR interleaved
+__global__ void k_ycc2bgr(const uint8_t* __restrict__ Y, const uint8_t* __restrict__ CR, const uint8_t* __restrict__ CB,
+                          uint8_t* __restrict__ bgr, size_t npx, int c0, int c1, int c2, int c3) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= npx) return;
+  const int y = Y[i], cr = (int)CR[i] - 128, cb = (int)CB[i] - 128;
+  bgr[3 * i] = sat_u8(y + descale_i(cb * c3, 14));
+  bgr[3 * i + 1] = sat_u8(y + descale_i(cb * c2 + cr * c1, 14));
+  bgr[3 * i + 2] = sat_u8(y + descale_i(cr * c0, 14));
+}
+
+// cv.resize INTER_CUBIC on CV_8U (gprsr.py:60-61, agpr.py:152-153: the chroma planes): 11-bit fixed-point taps
+// (host tables, cvRound(coef * 2048)), integer horizontal and vertical passes, (x + 2^21) >> 22, saturate.
+__global__ void k_resample_u8(const uint8_t* __restrict__ src, int Ws, uint8_t* __restrict__ dst, int Hd, int Wd,
+                              const int32_t* __restrict__ xi, const int32_t* __restrict__ xa,
+                              const int32_t* __restrict__ yi, const int32_t* __restrict__ ya) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)Hd * Wd) return;
+  const int r = (int)(idx / Wd), c = (int)(idx % Wd);
+  long long acc = 0;
+  for (int k = 0; k < 4; ++k) {
+    const uint8_t* row = src + (size_t)yi[4 * r + k] * Ws;
+    int h = 0;
+    for (int j = 0; j < 4; ++j) h += (int)row[xi[4 * c + j]] * xa[4 * c + j];
+    acc += (long long)h * ya[4 * r + k];
+  }
+  const long long v = (acc + (1ll << 21)) >> 22;
+  dst[idx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+// ------------------------------------------------ PSNR / SSIM (evaluation.py:83-98, skimage.metrics restated)
+// Two uint8 grey images, cropped by `crop` px on every side (Evaluator.preprocess_image).  PSNR needs the sum of
+// squared errors: integers, exact in 64 bits whatever the order.  SSIM = mean over all 7x7 windows that lie inside
+// the cropped image of S(window) (skimage: uniform filter, then crop 3 px = exactly those windows); the five
+// window sums are integers too, S is float64, and the mean is reduced in a fixed order (per-workgroup tree ->
+// one partial per workgroup -> k_metrics_final sums them serially per lane, then a tree): deterministic.
+#define MET_THREADS 256
+__global__ void __launch_bounds__(MET_THREADS)
+k_metrics_partial(const uint8_t* __restrict__ a, const uint8_t* __restrict__ b, int W, int crop, int Hc, int Wc,
+                  unsigned long long* __restrict__ sse_part, double* __restrict__ ssim_part) {
+  __shared__ unsigned long long sq[MET_THREADS];
+  __shared__ double ss[MET_THREADS];
+  const int tid = threadIdx.x;
+  const size_t idx = (size_t)blockIdx.x * MET_THREADS + tid;
+  unsigned long long e2 = 0;
+  double S = 0.0;
+  if (idx < (size_t)Hc * Wc) {
+    const int i = (int)(idx / Wc), j = (int)(idx % Wc);
+    const uint8_t* pa = a + (size_t)(crop + i) * W + crop + j;
+    const uint8_t* pb = b + (size_t)(crop + i) * W + crop + j;
+    const int d = (int)pa[0] - (int)pb[0];
+    e2 = (unsigned long long)(d * d);
+    if (i + 7 <= Hc && j + 7 <= Wc) {   // window with top-left corner (i, j)
+      int sa = 0, sb = 0, saa = 0, sbb = 0, sab = 0;
+      for (int u = 0; u < 7; ++u)
+        for (int v = 0; v < 7; ++v) {
+          const int x = pa[(size_t)u * W + v], y = pb[(size_t)u * W + v];
+          sa += x; sb += y; saa += x * x; sbb += y * y; sab += x * y;
+        }
+      const double ux = sa / 49.0, uy = sb / 49.0, uxx = saa / 49.0, uyy = sbb / 49.0, uxy = sab / 49.0;
+      const double cn = 49.0 / 48.0;
+      const double vx = cn * (uxx - ux * ux), vy = cn * (uyy - uy * uy), vxy = cn * (uxy - ux * uy);
+      const double C1 = (0.01 * 255) * (0.01 * 255), C2 = (0.03 * 255) * (0.03 * 255);
+      S = ((2 * ux * uy + C1) * (2 * vxy + C2)) / ((ux * ux + uy * uy + C1) * (vx + vy + C2));
+    }
+  }
+  sq[tid] = e2; ss[tid] = S;
+  __syncthreads();
+  for (int o = MET_THREADS / 2; o > 0; o >>= 1) {
+    if (tid < o) { sq[tid] += sq[tid + o]; ss[tid] += ss[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) { sse_part[blockIdx.x] = sq[0]; ssim_part[blockIdx.x] = ss[0]; }
+}
+
+// out[0] = PSNR (dB, data_range 255; +inf for identical images), out[1] = mean SSIM, out[2] = MSE
+__global__ void __launch_bounds__(MET_THREADS)
+k_metrics_final(const unsigned long long* __restrict__ sse_part, const double* __restrict__ ssim_part, int nparts,
+                double npix, double nwin, double* __restrict__ out) {
+  __shared__ unsigned long long sq[MET_THREADS];
+  __shared__ double ss[MET_THREADS];
+  const int tid = threadIdx.x;
+  unsigned long long e2 = 0;
+  double S = 0.0;
+  for (int p = tid; p < nparts; p += MET_THREADS) { e2 += sse_part[p]; S += ssim_part[p]; }
+  sq[tid] = e2; ss[tid] = S;
+  __syncthreads();
+  for (int o = MET_THREADS / 2; o > 0; o >>= 1) {
+    if (tid < o) { sq[tid] += sq[tid + o]; ss[tid] += ss[tid + o]; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double mse = (double)sq[0] / npix;
+    out[0] = 10.0 * log10(255.0 * 255.0 / mse);
+    out[1] = nwin > 0 ? ss[0] / nwin : 0.0;
+    out[2] = mse;
+  }
 }

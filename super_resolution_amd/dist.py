@@ -9,6 +9,7 @@ full HR image -- it needs the whole phase-1 image for the blur/downsample that
 feeds phase 2 (gprsr.py:85-87).  torch.distributed backend "nccl" is RCCL over
 xGMI on ROCm; "gloo" is used for the CPU tests of this logic.
 """
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -20,28 +21,69 @@ def shard_range(B, rank, world):
     return lo, lo + q + (1 if rank < r else 0)
 
 
-def all_gather_rows(local, B, world, group=None, force_collective=False):
-    """local: this rank's [hi-lo, ...] slice (shard_range order) -> the full [B, ...] tensor on every rank.
-    force_collective: run the collective even for world == 1 (used by the single-GPU RCCL smoke test)."""
+def deal_chains(lens, world):
+    """Owner rank of each warm-start chain (a chain is serial and stays on one GPU): longest chain first,
+    each to the rank with the least work so far.  Deterministic: every rank computes the same table."""
+    load = [0] * world
+    owner = [0] * len(lens)
+    for j in sorted(range(len(lens)), key=lambda j: (-lens[j], j)):
+        r = min(range(world), key=lambda r: (load[r], r))
+        owner[j] = r
+        load[r] += lens[j]
+    return owner
+
+
+def exchange_rows(locals_, owned, B, rank, world, group=None, force_collective=False):
+    """The one collective of the path.  Every rank holds, for each tensor of `locals_`, the rows it computed
+    (row i of the local tensor = global row owned[rank][i]); returns the full [B, ...] tensors on every rank.
+    The row payloads of all tensors are packed byte-wise into one buffer of max-rows-per-rank rows, exchanged
+    with a single all_gather_into_tensor (RCCL all-gather over xGMI; no list API, no per-tensor collectives)
+    and scattered to their global rows.  owned: list over ranks of int64 index arrays (known to every rank).
+    A rank that owns nothing sends an all-padding buffer.  force_collective: also for world == 1 (RCCL smoke)."""
+    cnt = len(owned[rank])
+    for t in locals_:
+        assert t.shape[0] == cnt, (t.shape, cnt)
     if world == 1 and not force_collective:
-        return local
-    cap = (B + world - 1) // world
-    tail = local.shape[1:]
-    buf = torch.zeros((cap,) + tuple(tail), dtype=local.dtype, device=local.device)
-    buf[:local.shape[0]] = local
-    if dist.get_backend(group) == "gloo" and buf.is_cuda:   # rehearsal path: gloo moves host memory
-        hbuf = buf.cpu()
-        hparts = [torch.empty_like(hbuf) for _ in range(world)]
-        dist.all_gather(hparts, hbuf, group=group)
-        parts = [p.to(buf.device) for p in hparts]
+        outs = []
+        for t in locals_:
+            o = torch.empty((B,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+            o.index_copy_(0, torch.as_tensor(owned[0]).to(t.device), t)
+            outs.append(o)
+        return outs
+    dev = locals_[0].device
+    cap = max(1, max(len(o) for o in owned))
+    widths = [int(np_prod(t.shape[1:])) * t.element_size() for t in locals_]
+    row_bytes = (sum(widths) + 15) // 16 * 16
+    buf = torch.zeros((cap, row_bytes), dtype=torch.uint8, device=dev)
+    col = 0
+    for t, w in zip(locals_, widths):
+        if cnt:
+            buf[:cnt, col:col + w] = t.contiguous().view(cnt, -1).view(torch.uint8).view(cnt, w)
+        col += w
+    out = torch.empty((world * cap, row_bytes), dtype=torch.uint8, device=dev)
+    if dist.get_backend(group) == "gloo" and buf.is_cuda:   # one-GPU rehearsal: gloo moves host memory
+        hout = torch.empty(out.shape, dtype=torch.uint8)
+        dist.all_gather_into_tensor(hout, buf.cpu(), group=group)
+        out = hout.to(dev)
     else:
-        parts = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(parts, buf, group=group)
-    out = torch.empty((B,) + tuple(tail), dtype=local.dtype, device=local.device)
-    for r in range(world):
-        lo, hi = shard_range(B, r, world)
-        out[lo:hi] = parts[r][:hi - lo]
-    return out
+        dist.all_gather_into_tensor(out, buf, group=group)
+    src = np.concatenate([r * cap + np.arange(len(o), dtype=np.int64) for r, o in enumerate(owned)])
+    dst = np.concatenate([np.asarray(o, dtype=np.int64) for o in owned])
+    assert dst.size == B and np.array_equal(np.sort(dst), np.arange(B)), "every global row must have exactly one owner"
+    perm = torch.as_tensor(src[np.argsort(dst)]).to(dev)
+    rows = out.index_select(0, perm)                       # [B, row_bytes] in global row order
+    outs, col = [], 0
+    for t, w in zip(locals_, widths):
+        outs.append(rows[:, col:col + w].contiguous().view(t.dtype).view((B,) + tuple(t.shape[1:])))
+        col += w
+    return outs
+
+
+def np_prod(shape):
+    p = 1
+    for v in shape:
+        p *= int(v)
+    return p
 
 
 def init_from_env(backend=None):

@@ -9,12 +9,13 @@ HIP kernels behind include/gpsr.h.  Device tensors in, device tensors out.
 Warm start.  In the reference the kernel objects are module-level singletons
 (kernels.py:7-13) and only the RBF branch resets lengthscale/outputscale per
 patch (gprsr.py:167-172); for the other kernels patch k starts Adam from patch
-k-1's optimum -- a serial chain.
-  warm_start="independent" (default): every patch starts from the
-      fresh-process values (raw 0), patches are independent, batched, sharded.
-  warm_start="chain": the reference's literal behaviour, one GP after the other
-      (B=1 launches, hyper-parameters carried on the device).  Validation only.
-For RBF both are the same thing.
+k-1's optimum -- a serial chain.  predict_pixels_batch does both:
+  chain_carry=None   every patch starts from the fresh-process values (raw 0):
+      independent GPs, one batch, patch-sharded across GPUs;
+  chain_carry=[jobs,4]   every job (image) is one chain over its patches; link k of
+      all chains is one batched launch sequence (BatchedGP.fit_predict_chains),
+      whole chains are dealt to the ranks.
+GPRSR (gprsr.py) maps its warm_start modes onto these.  For RBF both are the same.
 """
 import numpy as np
 import torch
@@ -80,12 +81,10 @@ class BatchedGP:
         per = _lib.load().gpsr_fit_workspace_bytes(1, n, d)
         return max(1, min(B, int(self.max_workspace_bytes // per)))
 
-    def fit_predict(self, X, y, Xs, init_raw=(0.0, 0.0), chain_kernel=None):
-        """X [B,n,8], y [B,n], Xs [B,m,8] -> pred [B,m], raw [B,4], flags [B]."""
+    def fit_predict(self, X, y, Xs, init_raw=(0.0, 0.0)):
+        """Independent GPs.  X [B,n,8], y [B,n], Xs [B,m,8] -> pred [B,m], raw [B,4], flags [B]."""
         B, n, d = X.shape
         dev = X.device
-        if chain_kernel is not None:
-            return self._fit_predict_chain(X, y, Xs, chain_kernel)
         raw = ops.init_hypers(y, self.kernel_id, init_raw[0], init_raw[1])
         pred = torch.empty((B, Xs.shape[1]), dtype=torch.float64, device=dev)
         flags = torch.empty(B, dtype=torch.int32, device=dev)
@@ -98,40 +97,66 @@ class BatchedGP:
             flags[b0:b1] = fl
         return pred, raw, flags
 
-    def _fit_predict_chain(self, X, y, Xs, kern):
-        """Serial warm-start chain: GP b starts from GP b-1's outputscale/lengthscale;
-        the chain enters and leaves through the kernel object's raw values."""
+    def fit_predict_chains(self, X, y, Xs, lens, carry):
+        """Warm-start chains: the GPs are the concatenation of len(lens) chains, chain j holding
+        lens[j] consecutive GPs.  Inside a chain GP k starts Adam from GP k-1's raw outputscale / lengthscale
+        (the reference's kernel singleton, kernels.py:7-13 + gprsr.py:153-174); the chains do not see each
+        other, so link k of every chain that is still running is fitted in ONE batched launch sequence.
+        carry [len(lens),4] float32 (device, columns 2,3 used): what each chain starts from; on return, what
+        each chain ended with (fed to the next predict_pixels pass of the same image)."""
         B, n, d = X.shape
         dev = X.device
+        m = Xs.shape[1]
+        nch = len(lens)
+        assert sum(lens) == B and carry.shape == (nch, 4)
+        pred = torch.empty((B, m), dtype=torch.float64, device=dev)
         raw = torch.empty((B, 4), dtype=torch.float32, device=dev)
-        pred = torch.empty((B, Xs.shape[1]), dtype=torch.float64, device=dev)
         flags = torch.empty(B, dtype=torch.int32, device=dev)
-        ws = self._workspace(1, n, d, dev)
-        for b in range(B):
-            if b == 0:
-                r = ops.init_hypers(y[0:1], self.kernel_id, kern.raw_outputscale, kern.base_kernel.raw_parameter)
-            else:
-                r = ops.init_hypers(y[b:b + 1], self.kernel_id, carry=raw[b - 1])
-            alpha, fl = ops.fit(X[b:b + 1], y[b:b + 1], self.kernel_id, r, self.iters, self.lr, ws)
-            pred[b:b + 1] = ops.predict(X[b:b + 1], Xs[b:b + 1], alpha, r, self.kernel_id)
-            raw[b] = r[0]
-            flags[b] = fl[0]
-        last = raw[B - 1].cpu()
-        kern.raw_outputscale = float(last[2])
-        kern.base_kernel.raw_parameter = float(last[3])
+        if B == 0:
+            return pred, raw, flags
+        # longest chain first: the chains still running at link k are then a prefix of `order`
+        order = sorted(range(nch), key=lambda j: -lens[j])
+        offs = np.concatenate([[0], np.cumsum(lens)])[:-1]
+        steps, flat = [], []
+        for k in range(max(lens)):
+            act = [j for j in order if lens[j] > k]
+            steps.append(len(act))
+            flat.extend(int(offs[j]) + k for j in act)
+        idx_all = torch.as_tensor(np.asarray(flat, dtype=np.int64)).to(dev)
+        order_t = torch.as_tensor(np.asarray(order, dtype=np.int64)).to(dev)
+        cur = carry.index_select(0, order_t).contiguous()      # [nch,4] in `order`
+        ws = self._workspace(min(nch, B), n, d, dev)
+        pos = 0
+        for k, bk in enumerate(steps):
+            idx = idx_all[pos:pos + bk]
+            pos += bk
+            Xk, yk, Xsk = X.index_select(0, idx), y.index_select(0, idx), Xs.index_select(0, idx)
+            r = ops.init_hypers(yk, self.kernel_id, carry=cur[:bk])
+            alpha, fl = ops.fit(Xk, yk, self.kernel_id, r, self.iters, self.lr, ws)
+            pred.index_copy_(0, idx, ops.predict(Xk, Xsk, alpha, r, self.kernel_id))
+            raw.index_copy_(0, idx, r)
+            flags.index_copy_(0, idx, fl)
+            cur[:bk] = r
+        carry.index_copy_(0, order_t, cur)
         return pred, raw, flags
 
 
 def predict_pixels_batch(jobs, s, p, gp, stride_percentage=0.9, use_all_pixels=True, mode=ops.AVERAGE,
-                         chain_kernel=None, stats=None, shard=None):
+                         chain_carry=None, stats=None, shard=None):
     """jobs: list of (training_input, training_target, test_input) device float64
     images (gprsr.py:126).  All patches of all jobs form ONE batch of GPs.
     Returns the list of recombined, clipped HR images.
 
-    shard=(rank, world): this rank fits only its contiguous slice of the global
-    patch list and the predicted patch interiors are all-gathered (RCCL) before
-    recombination -- the only exchange on the path.
+    chain_carry=None: independent GPs.  chain_carry = float32 [len(jobs),4] device tensor: every job is a
+    warm-start chain over its patches in PatchHandler order (BatchedGP.fit_predict_chains); row j is what chain
+    j starts from and, on return, what it ended with.
+
+    shard=(rank, world): independent GPs -- this rank fits a contiguous slice of the global patch list;
+    chains -- this rank fits whole jobs (a chain is serial; the jobs are dealt out longest first).  The
+    predicted patch interiors (+ raw hyper-parameters and flags, packed into the same rows) are exchanged
+    with ONE all-gather (RCCL) before recombination -- the only collective on the path.
     """
+    from . import dist as gdist
     dev = jobs[0][0].device
     tidx = torch.as_tensor(training_indices(p, use_all_pixels)).to(dev)
     geo = []
@@ -142,37 +167,65 @@ def predict_pixels_batch(jobs, s, p, gp, stride_percentage=0.9, use_all_pixels=T
         assert p <= H and p <= W, f"Patch size {p} is too big for image size {(H, W)}"
         rows, cols, locs = _geometry(H, W, s, p, stride_percentage)
         geo.append((H, W, rows, cols, locs))
-    B = sum(g[4].shape[0] for g in geo)
+    lens = [g[4].shape[0] for g in geo]
+    offs = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    B = int(offs[-1])
     rank, world = shard if shard is not None else (0, 1)
-    from .dist import shard_range
-    g0, g1 = shard_range(B, rank, world)
-    # gather only this rank's slice of the global (job-major, row-major) patch list
-    Xl, yl, Xsl, off = [], [], [], 0
-    for (tin, ttg, tst), (H, W, rows, cols, locs) in zip(jobs, geo):
-        nb = locs.shape[0]
-        lo, hi = max(g0, off) - off, min(g1, off + nb) - off
-        if hi > lo:
-            X, y, Xs = ops.gather(tin, ttg, tst, s, p, torch.as_tensor(np.ascontiguousarray(locs[lo:hi])).to(dev), tidx)
+    nt = int(tidx.shape[0])
+    n, m = nt * nt, (p * s - 2) ** 2
+    # which global patch indices each rank owns (every rank computes the whole table: no communication)
+    if chain_carry is None:
+        owned = [np.arange(*gdist.shard_range(B, r, world), dtype=np.int64) for r in range(world)]
+        my_jobs = None
+    else:
+        assert chain_carry.shape == (len(jobs), 4) and chain_carry.dtype == torch.float32
+        owner = gdist.deal_chains(lens, world)
+        job_lists = [[j for j in range(len(jobs)) if owner[j] == r] for r in range(world)]
+        owned = [np.concatenate([np.arange(offs[j], offs[j + 1]) for j in jl]) if jl else np.zeros(0, np.int64)
+                 for jl in job_lists]
+        my_jobs = job_lists[rank]
+    mine = owned[rank]
+    # gather this rank's patches, job by job
+    Xl, yl, Xsl = [], [], []
+    for j, ((tin, ttg, tst), (H, W, rows, cols, locs)) in enumerate(zip(jobs, geo)):
+        sel = mine[(mine >= offs[j]) & (mine < offs[j + 1])] - offs[j]
+        if sel.size:
+            X, y, Xs = ops.gather(tin, ttg, tst, s, p, torch.as_tensor(np.ascontiguousarray(locs[sel])).to(dev), tidx)
             Xl.append(X); yl.append(y); Xsl.append(Xs)
-        off += nb
-    X = torch.cat(Xl) if len(Xl) > 1 else Xl[0]
-    y = torch.cat(yl) if len(yl) > 1 else yl[0]
-    Xs = torch.cat(Xsl) if len(Xsl) > 1 else Xsl[0]
+    if Xl:
+        X = torch.cat(Xl) if len(Xl) > 1 else Xl[0]
+        y = torch.cat(yl) if len(yl) > 1 else yl[0]
+        Xs = torch.cat(Xsl) if len(Xsl) > 1 else Xsl[0]
+    else:   # a rank without work (fewer patches / chains than ranks) still takes part in the exchange
+        X = torch.empty((0, n, 8), dtype=torch.float64, device=dev)
+        y = torch.empty((0, n), dtype=torch.float64, device=dev)
+        Xs = torch.empty((0, m, 8), dtype=torch.float64, device=dev)
     del Xl, yl, Xsl
-    pred, raw, flags = gp.fit_predict(X, y, Xs, chain_kernel=chain_kernel)
+    if chain_carry is None:
+        if X.shape[0]:
+            pred, raw, flags = gp.fit_predict(X, y, Xs)
+        else:
+            pred = torch.empty((0, m), dtype=torch.float64, device=dev)
+            raw = torch.empty((0, 4), dtype=torch.float32, device=dev)
+            flags = torch.empty(0, dtype=torch.int32, device=dev)
+    else:
+        mj = torch.as_tensor(np.asarray(my_jobs, dtype=np.int64)).to(dev)
+        carry_l = chain_carry.index_select(0, mj).contiguous()
+        pred, raw, flags = gp.fit_predict_chains(X, y, Xs, [lens[j] for j in my_jobs], carry_l)
+        if world > 1:
+            carry_all = gdist.exchange_rows([carry_l], [np.asarray(jl, dtype=np.int64) for jl in job_lists],
+                                            len(jobs), rank, world)[0]
+            chain_carry.copy_(carry_all)
+        else:
+            chain_carry.index_copy_(0, mj, carry_l)
     if world > 1:
-        from .dist import all_gather_rows
-        pred = all_gather_rows(pred, B, world)
-        raw = all_gather_rows(raw, B, world)
-        flags = all_gather_rows(flags, B, world)
+        pred, raw, flags = gdist.exchange_rows([pred, raw, flags], owned, B, rank, world)
     if stats is not None:
         stats.raw.append(raw)
         stats.flags.append(flags)
-    outs, b0 = [], 0
-    for (tin, ttg, tst), (H, W, rows, cols, locs) in zip(jobs, geo):
-        nb = locs.shape[0]
-        out = ops.combine(pred[b0:b0 + nb], tst, H, W, s, p, torch.as_tensor(rows).to(dev),
+    outs = []
+    for j, ((tin, ttg, tst), (H, W, rows, cols, locs)) in enumerate(zip(jobs, geo)):
+        out = ops.combine(pred[offs[j]:offs[j + 1]], tst, H, W, s, p, torch.as_tensor(rows).to(dev),
                           torch.as_tensor(cols).to(dev), mode, clip=True)
         outs.append(out)
-        b0 += nb
     return outs

@@ -7,8 +7,8 @@ upsample / blur_downsample / deblur / predict_pixels.  numpy arrays in, fresh
 numpy arrays out; internally the image goes to the GPU once and stays there
 through upsample -> blur/downsample -> deblur and through x4 = x2 o x2.
 
-Additional (keyword-only) knobs of the engine: warm_start ("independent" |
-"chain", see engine.py), iters, and the batch entry points
+Additional (keyword-only) knobs of the engine: warm_start ("chain" = the reference's
+semantics and the default | "chain_per_image" | "independent", see class GPRSR), iters, and the batch entry points
 apply_for_channel_batch / apply_batch that fit the patches of many images in
 one GP batch.
 """
@@ -59,9 +59,21 @@ def _device():
 
 
 class GPRSR:
+    """warm_start (keyword-only; the reference has no such switch, it IS "chain"):
+      "chain"            the reference's behaviour: its kernel objects are module singletons (kernels.py:7-13)
+                         and only RBF re-initialises outputscale / lengthscale per patch (gprsr.py:167-172), so every
+                         patch starts Adam from the previous patch's optimum -- across patches, the two phases,
+                         channels, images and GPRSR instances, through `used_kernel`.  Serial by definition.
+      "chain_per_image"  every image is processed as the reference processes the FIRST image of a fresh process
+                         (chain from the initial raw 0, the singleton is neither read nor written): the images of
+                         a batch are independent chains and link k of all of them is one batched launch sequence.
+      "independent"      every patch starts from the initial raw 0: the batched / patch-sharded engine of the
+                         north star.  A different algorithm at pixel level for non-RBF kernels.
+    For RBF the three coincide."""
+
     def __init__(self, scaling_factor, used_kernel=matern52_kernel, color_mode=ColorSpace.YUV, *,
-                 warm_start="independent", iters=50, shard=None, max_workspace_bytes=48 << 30):
-        assert warm_start in ("independent", "chain")
+                 warm_start="chain", iters=50, shard=None, max_workspace_bytes=48 << 30):
+        assert warm_start in ("independent", "chain", "chain_per_image")
         self.scaling_factor = scaling_factor
         self.current_scaling_factor = None
         self.used_kernel = used_kernel
@@ -71,25 +83,35 @@ class GPRSR:
         self.shard = shard
         self.stats = engine.FitStats()
         self.check_failures = True
+        self._carry = None          # [n_images,4] float32 device tensor while a chained call runs
+        self._scoped_carry = None   # chain_per_image: the carry of the image apply() is working on (BGR: 3 channels)
         self._gp = engine.BatchedGP(kernel_id_of(used_kernel), iters=iters, lr=LEARNING_RATE,
                                     max_workspace_bytes=max_workspace_bytes)
+
+    def _chained(self):
+        return self.warm_start != "independent" and self._gp.kernel_id != ops.RBF
 
     # ------------------------------------------------------------------ colour handling (gprsr.py:48-74)
     def apply(self, lr_image):
         if DO_TIMING:
             start_time = time.time()
-        if self.color_mode == ColorSpace.GRAYSCALE:
-            g = self.apply_for_channel(imgproc.bgr2gray(lr_image))
-            img_out = np.stack([g, g, g], axis=-1)
-        elif self.color_mode == ColorSpace.YUV:
-            y, u, v = imgproc.bgr2yuv(lr_image)
-            y = self.apply_for_channel(y)
-            u = imgproc.resize_cubic_u8(u, fx=self.scaling_factor, fy=self.scaling_factor)
-            v = imgproc.resize_cubic_u8(v, fx=self.scaling_factor, fy=self.scaling_factor)
-            img_out = imgproc.yuv2bgr(y, u, v)
-        else:
-            chans = [self.apply_for_channel(np.ascontiguousarray(lr_image[..., i])) for i in range(3)]
-            img_out = np.stack(chans, axis=-1)
+        if self.warm_start == "chain_per_image" and self._chained():
+            self._scoped_carry = torch.zeros((1, 4), dtype=torch.float32, device=_device())
+        try:
+            if self.color_mode == ColorSpace.GRAYSCALE:
+                g = self.apply_for_channel(imgproc.bgr2gray(lr_image))
+                img_out = np.stack([g, g, g], axis=-1)
+            elif self.color_mode == ColorSpace.YUV:
+                y, u, v = imgproc.bgr2yuv(lr_image)
+                y = self.apply_for_channel(y)
+                u = imgproc.resize_cubic_u8(u, fx=self.scaling_factor, fy=self.scaling_factor)
+                v = imgproc.resize_cubic_u8(v, fx=self.scaling_factor, fy=self.scaling_factor)
+                img_out = imgproc.yuv2bgr(y, u, v)
+            else:
+                chans = [self.apply_for_channel(np.ascontiguousarray(lr_image[..., i])) for i in range(3)]
+                img_out = np.stack(chans, axis=-1)
+        finally:
+            self._scoped_carry = None
         if DO_TIMING:
             print("Upscaling took %s seconds" % (time.time() - start_time), flush=True)
         return img_out
@@ -111,11 +133,19 @@ class GPRSR:
         self.stats holds the raw hyper-parameters and failure flags of this call's predict_pixels passes;
         a flagged GP raises engine.NotPSDError (the reference's failure mode) unless check_failures is False."""
         self.stats = engine.FitStats()
-        scaling_factor = self.scaling_factor
-        while scaling_factor >= 4:
-            scaling_factor /= 2
-            imgs = self._do_algorithm(imgs, 2)
-        outs = self._do_algorithm(imgs, scaling_factor)
+        if not self._chained():
+            outs = self._run(imgs, None)
+        elif self.warm_start == "chain":
+            # image after image, each continuing the chain the kernel singleton holds (gprsr.py:217-227 loop)
+            outs = []
+            for im in imgs:
+                carry = self._singleton_carry(im.device)
+                outs.append(self._run([im], carry)[0])
+                self._store_singleton(carry)
+        else:
+            carry = self._scoped_carry if (self._scoped_carry is not None and len(imgs) == 1) else \
+                torch.zeros((len(imgs), 4), dtype=torch.float32, device=imgs[0].device)
+            outs = self._run(imgs, carry)
         if self.check_failures:
             bad = [int(f.sum()) for f in self.stats.flags]   # one device sync, at the end of the call
             if any(bad):
@@ -123,11 +153,29 @@ class GPRSR:
                                          f"(per predict_pixels pass: {bad}); see GPRSR.stats.flags")
         return outs
 
+    def _singleton_carry(self, dev):
+        k = self.used_kernel
+        return torch.tensor([[0.0, 0.0, k.raw_outputscale, k.base_kernel.raw_parameter]], dtype=torch.float32, device=dev)
+
+    def _store_singleton(self, carry):
+        last = carry[0].cpu()
+        self.used_kernel.raw_outputscale = float(last[2])
+        self.used_kernel.base_kernel.raw_parameter = float(last[3])
+
+    def _run(self, imgs, carry):
+        """gprsr.py:91-98 on device images: x s recursion, upsample -> blur/downsample -> deblur."""
+        self._carry = carry
+        try:
+            scaling_factor = self.scaling_factor
+            while scaling_factor >= 4:
+                scaling_factor /= 2
+                imgs = self._do_algorithm(imgs, 2)
+            return self._do_algorithm(imgs, scaling_factor)
+        finally:
+            self._carry = None
+
     def _do_algorithm(self, imgs, scaling_factor):
         self.current_scaling_factor = scaling_factor
-        if self.warm_start == "chain" and len(imgs) > 1:
-            # the chain runs image by image: upsample(i), deblur(i), upsample(i+1), ...
-            return [self._do_algorithm([im], scaling_factor)[0] for im in imgs]
         blurred_high = self._upsample(imgs)
         blurred_low = [self._blur_downsample(b) for b in blurred_high]
         return self._predict_pixels(list(zip(blurred_low, imgs, blurred_high)))
@@ -150,16 +198,31 @@ class GPRSR:
         s = self._s_int()
         p = int(self.current_scaling_factor * 10)
         mode = PATCH_INTERPOLATION.value
-        chain = self.used_kernel if (self.warm_start == "chain" and self._gp.kernel_id != ops.RBF) else None
         return engine.predict_pixels_batch(jobs, s, p, self._gp, STRIDE_PERCENTAGE, USE_ALL_PIXELS_FOR_TRAINING,
-                                           mode, chain_kernel=chain, stats=self.stats, shard=self.shard)
+                                           mode, chain_carry=self._carry, stats=self.stats, shard=self.shard)
 
     # ------------------------------------------------------------------ reference-named numpy methods
     def _to_dev(self, a):
         return torch.as_tensor(np.ascontiguousarray(a, dtype=np.float64)).to(_device())
 
+    def _stage(self, fn):
+        """A reference-named stage called on its own: chained modes read and write the kernel singleton
+        ("chain") or start from raw 0 ("chain_per_image"), like one predict_pixels call of the reference."""
+        if not self._chained() or self._carry is not None:
+            return fn()
+        dev = _device()
+        self._carry = self._singleton_carry(dev) if self.warm_start == "chain" else \
+            torch.zeros((1, 4), dtype=torch.float32, device=dev)
+        try:
+            out = fn()
+            if self.warm_start == "chain":
+                self._store_singleton(self._carry)
+            return out
+        finally:
+            self._carry = None
+
     def upsample(self, img):
-        return self._upsample([self._to_dev(img)])[0].cpu().numpy()
+        return self._stage(lambda: self._upsample([self._to_dev(img)])[0].cpu().numpy())
 
     def blur_downsample(self, img):
         return self._blur_downsample(self._to_dev(img)).cpu().numpy()
@@ -171,4 +234,4 @@ class GPRSR:
         assert training_input.shape == training_target.shape
         assert test_input.shape[0] == training_input.shape[0] * self.current_scaling_factor
         job = (self._to_dev(training_input), self._to_dev(training_target), self._to_dev(test_input))
-        return self._predict_pixels([job])[0].cpu().numpy()
+        return self._stage(lambda: self._predict_pixels([job])[0].cpu().numpy())

@@ -73,7 +73,7 @@ class PatchHandler:
         from . import ops
         P = patches[0].shape[0]
         s = int(P / self.base_patch_size)
-        dev = torch.device("cuda:0")
+        dev = torch.device("cuda", torch.cuda.current_device())   # one process per GPU: the rank's own device
         stack = torch.as_tensor(np.ascontiguousarray(np.stack(patches), dtype=np.float64)).to(dev)
         rows = torch.as_tensor(self.rows).to(dev)
         cols = torch.as_tensor(self.cols).to(dev)

@@ -116,8 +116,10 @@ def _descale(x, n):
 
 
 def bgr2gray(bgr):
-    c = bgr.astype(np.int32)
-    return _descale(c[..., 0] * 1868 + c[..., 1] * 9617 + c[..., 2] * 4899, 14).astype(np.uint8)
+    """cv.cvtColor(COLOR_BGR2GRAY), uint8: OpenCV's 15-bit RGB2Gray table (3735, 19235, 9798, >> 15); the YUV /
+    YCrCb conversions below use the 14-bit one.  Pinned by the reference's own *_GPR_matern52_gray.png outputs."""
+    c = bgr.astype(np.int64)
+    return _descale(c[..., 0] * 3735 + c[..., 1] * 19235 + c[..., 2] * 9798, 15).astype(np.uint8)
 
 
 def _split_ycc(bgr, cr_coef, cb_coef):

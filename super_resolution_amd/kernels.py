@@ -122,7 +122,7 @@ class GeneralModel:
         import torch
         self.covar_module = covar_module
         self.kernel_id = kernel_id_of(covar_module)
-        dev = torch.device("cuda:0")
+        dev = torch.device("cuda", torch.cuda.current_device())   # one process per GPU: the rank's own device
         self.train_x = torch.as_tensor(np.asarray(train_x, dtype=np.float64)).to(dev).contiguous()
         self.train_y = torch.as_tensor(np.asarray(train_y, dtype=np.float64)).to(dev).contiguous()
         self.raw = torch.tensor([[0.0, 0.0, covar_module.raw_outputscale, covar_module.base_kernel.raw_parameter]],

@@ -23,6 +23,10 @@ def _p(t, dtype=None):
         return None
     if not t.is_cuda:
         raise _lib.GpsrError("gpsr ops need device tensors (no CPU fallback)")
+    if t.device.index != torch.cuda.current_device():
+        # launches go on the current device's stream (_stream): a buffer of another GPU would fault there
+        raise _lib.GpsrError(f"tensor on {t.device}, current device is cuda:{torch.cuda.current_device()} "
+                             "(one process per GPU: torch.cuda.set_device(LOCAL_RANK) first)")
     if dtype is not None and t.dtype != dtype:
         raise _lib.GpsrError(f"expected {dtype}, got {t.dtype}")
     if not t.is_contiguous():
@@ -51,11 +55,17 @@ def gather(train_in, train_tgt, test_in, s, p, locs, tidx):
 
 
 def init_hypers(y, kernel_id, init_raw_os=0.0, init_raw_ls=0.0, carry=None):
+    """carry: None | [4] (every GP continues that one chain link) | [B,4] (GP b continues chain b)."""
     lib = _lib.load()
     B, n = y.shape
     raw = torch.empty((B, 4), dtype=torch.float32, device=y.device)
+    stride = 0
+    if carry is not None and carry.dim() == 2:
+        if carry.shape != (B, 4):
+            raise _lib.GpsrError(f"carry must be [4] or [{B},4], got {tuple(carry.shape)}")
+        stride = 4
     _lib.check(lib.gpsr_init_hypers(_p(y, torch.float64), B, n, kernel_id, float(init_raw_os), float(init_raw_ls),
-                                    _p(carry, torch.float32), _p(raw), _stream()), "gpsr_init_hypers")
+                                    _p(carry, torch.float32), stride, _p(raw), _stream()), "gpsr_init_hypers")
     return raw
 
 
@@ -262,6 +272,70 @@ def axpy(a, b, alpha):
     out = torch.empty_like(a)
     _lib.check(lib.gpsr_axpy(_p(a, torch.float64), _p(b, torch.float64), float(alpha), _p(out), a.numel(), _stream()),
                "gpsr_axpy")
+    return out
+
+
+# ------------------------------------------------------------ uint8 colour stages + metrics
+def bgr2gray(bgr):
+    """[H,W,3] uint8 device (cv.imread layout) -> [H,W] uint8   (gpsr_bgr2gray)."""
+    lib = _lib.load()
+    H, W, _ = bgr.shape
+    out = torch.empty((H, W), dtype=torch.uint8, device=bgr.device)
+    _lib.check(lib.gpsr_bgr2gray(_p(bgr, torch.uint8), _p(out), H * W, _stream()), "gpsr_bgr2gray")
+    return out
+
+
+def _split3(fn, name, bgr):
+    H, W, _ = bgr.shape
+    planes = [torch.empty((H, W), dtype=torch.uint8, device=bgr.device) for _ in range(3)]
+    _lib.check(fn(_p(bgr, torch.uint8), _p(planes[0]), _p(planes[1]), _p(planes[2]), H * W, _stream()), name)
+    return planes
+
+
+def _merge3(fn, name, a, b, c):
+    H, W = a.shape
+    out = torch.empty((H, W, 3), dtype=torch.uint8, device=a.device)
+    _lib.check(fn(_p(a, torch.uint8), _p(b, torch.uint8), _p(c, torch.uint8), _p(out), H * W, _stream()), name)
+    return out
+
+
+def bgr2yuv(bgr):
+    return _split3(_lib.load().gpsr_bgr2yuv, "gpsr_bgr2yuv", bgr)
+
+
+def yuv2bgr(y, u, v):
+    return _merge3(_lib.load().gpsr_yuv2bgr, "gpsr_yuv2bgr", y, u, v)
+
+
+def bgr2ycrcb(bgr):
+    return _split3(_lib.load().gpsr_bgr2ycrcb, "gpsr_bgr2ycrcb", bgr)
+
+
+def ycrcb2bgr(y, cr, cb):
+    return _merge3(_lib.load().gpsr_ycrcb2bgr, "gpsr_ycrcb2bgr", y, cr, cb)
+
+
+def resample_u8(img, Hd, Wd, xi, xa, yi, ya):
+    lib = _lib.load()
+    Hs, Ws = img.shape
+    out = torch.empty((Hd, Wd), dtype=torch.uint8, device=img.device)
+    _lib.check(lib.gpsr_resample_u8(_p(img, torch.uint8), Hs, Ws, _p(out), Hd, Wd, _p(xi, torch.int32),
+                                    _p(xa, torch.int32), _p(yi, torch.int32), _p(ya, torch.int32), _stream()),
+               "gpsr_resample_u8")
+    return out
+
+
+def metrics(a, b, crop):
+    """Two [H,W] uint8 device images -> device float64 [3] = (PSNR dB, SSIM, MSE) after cropping (gpsr_metrics)."""
+    lib = _lib.load()
+    H, W = a.shape
+    if b.shape != a.shape:
+        raise _lib.GpsrError(f"metrics: shapes differ {tuple(a.shape)} vs {tuple(b.shape)}")
+    nbytes = lib.gpsr_metrics_workspace_bytes(H, W, crop)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=a.device)
+    out = torch.empty(3, dtype=torch.float64, device=a.device)
+    _lib.check(lib.gpsr_metrics(_p(a, torch.uint8), _p(b, torch.uint8), H, W, crop, _p(out), _p(ws), nbytes, _stream()),
+               "gpsr_metrics")
     return out
 
 

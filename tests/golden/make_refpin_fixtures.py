@@ -1,0 +1,49 @@
+"""Fixtures that pin the oracle and the HIP path to OUTPUT IMAGES THE REFERENCE ITSELF COMMITTED
+(data files, not source).  Run in the build container only (reads /root/reference); the GPU box
+only sees the PNGs written here.
+
+  Set14/image_SRF_2/img_00{1,2}_SRF_2_LR.png                 -> refpin/x2_lr_00{1,2}.png   (colour, as cv.imread sees them)
+  Set14/image_SRF_2/img_00{1,2}_SRF_2_HR.png                 -> refpin/x2_hr_00{1,2}.png   (grey, metric target)
+  Set14/image_SRF_2/img_00{1,2}_SRF_2_GPR_matern52_gray.png  -> refpin/x2_ref_m52_gray_00{1,2}.png
+        file name = gprsr.py:221-222 with the committed defaults gprsr.py:17-22 (SRF 2, matern52, GRAYSCALE):
+        img_001 is the first image of a fresh process (kernel singletons at their initial values), img_002 the
+        second image of the same process (the chain carries over, kernels.py:7-13)
+  Set14/image_SRF_3/img_001_SRF_3_LR.png                     -> refpin/x3_lr_001.png       (colour)
+  Set14/image_SRF_3/img_001_SRF_3_GPR_{RBF,matern12}.png     -> refpin/x3_ref_{RBF,matern12}_001.png
+        (three equal channels: GRAYSCALE runs; RBF has no chain, gprsr.py:167-172)
+The reference's three-equal-channel outputs are stored as 8-bit grey PNGs (one channel, no conversion).
+"""
+import os
+import sys
+
+import numpy as np
+from PIL import Image
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from oracle import cvops
+
+REF = "/root/reference/Set14"
+OUT = os.path.join(HERE, "refpin")
+os.makedirs(OUT, exist_ok=True)
+
+
+def rgb(path):
+    return np.array(Image.open(path).convert("RGB"))
+
+
+def save_grey3(src, dst):
+    a = rgb(src)
+    assert np.array_equal(a[..., 0], a[..., 1]) and np.array_equal(a[..., 0], a[..., 2]), src
+    Image.fromarray(a[..., 0]).save(os.path.join(OUT, dst))
+
+
+for i in (1, 2):
+    Image.fromarray(rgb(f"{REF}/image_SRF_2/img_{i:03d}_SRF_2_LR.png")).save(f"{OUT}/x2_lr_{i:03d}.png")
+    hr = rgb(f"{REF}/image_SRF_2/img_{i:03d}_SRF_2_HR.png")[:, :, ::-1]
+    Image.fromarray(cvops.bgr2gray(hr)).save(f"{OUT}/x2_hr_{i:03d}.png")
+    save_grey3(f"{REF}/image_SRF_2/img_{i:03d}_SRF_2_GPR_matern52_gray.png", f"x2_ref_m52_gray_{i:03d}.png")
+Image.fromarray(rgb(f"{REF}/image_SRF_3/img_001_SRF_3_LR.png")).save(f"{OUT}/x3_lr_001.png")
+for tag in ("RBF", "matern12"):
+    save_grey3(f"{REF}/image_SRF_3/img_001_SRF_3_GPR_{tag}.png", f"x3_ref_{tag}_001.png")
+print("ok", sorted(os.listdir(OUT)))

@@ -1,6 +1,6 @@
 """RCCL smoke test on the one GPU of the box: a 1-rank "nccl" process group running the
-same collective calls the sharded path makes (dist.all_gather of the padded f64 / f32 /
-int32 slices).  The world-2 logic itself is covered on CPU with gloo (tests/test_host.py);
+same collective call the sharded path makes (one all_gather_into_tensor of the packed f64 / f32 /
+int32 rows).  The world-2 logic itself is covered on CPU with gloo (tests/test_host.py);
 8-GPU runs are the driver's."""
 import os
 import subprocess
@@ -23,9 +23,10 @@ g = torch.Generator(device=dev); g.manual_seed(1)
 pred = torch.randn((37, 1444), dtype=torch.float64, device=dev, generator=g)
 raw = torch.randn((37, 4), dtype=torch.float32, device=dev, generator=g)
 flags = torch.arange(37, dtype=torch.int32, device=dev)
-for t in (pred, raw, flags):
-    out = gdist.all_gather_rows(t, 37, 1, force_collective=True)
-    assert out.shape == t.shape and torch.equal(out, t)
+import numpy as np
+outs = gdist.exchange_rows([pred, raw, flags], [np.arange(37, dtype=np.int64)], 37, 0, 1, force_collective=True)
+for out, t in zip(outs, (pred, raw, flags)):
+    assert out.shape == t.shape and out.dtype == t.dtype and torch.equal(out, t)
 dist.barrier()
 torch.cuda.synchronize()
 dist.destroy_process_group()
@@ -54,9 +55,9 @@ torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
 imgs = [np.rint(natural_image(H, W, s) * 255).astype(np.uint8) for H, W, s in ((44, 40, 1), (47, 52, 2), (40, 41, 3))]
 dimgs = [ops.u8_to_unit(torch.as_tensor(im).to(dev)) for im in imgs]
-sharded = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, shard=(rank, world)).apply_for_channel_device(dimgs)
+sharded = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, warm_start="independent", shard=(rank, world)).apply_for_channel_device(dimgs)
 if rank == 0:
-    whole = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE).apply_for_channel_device(dimgs)
+    whole = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, warm_start="independent").apply_for_channel_device(dimgs)
     assert all(torch.equal(a, b) for a, b in zip(sharded, whole)), "sharded != unsharded"
     sys.stdout.write("shard-ok\n")
 dist.barrier()

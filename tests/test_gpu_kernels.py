@@ -273,7 +273,7 @@ def test_context_workspace_and_flag_count():
     raw_a = ops.init_hypers(y, ops.RBF)
     raw_b = raw_a.clone()
     alpha_a, flags_a = ops.fit(X, y, ops.RBF, raw_a, iters=4)
-    ctx = lib.gpsr_create(torch.cuda.current_device(), B, n)
+    ctx = lib.gpsr_create(torch.cuda.current_device(), B, n, 0)
     assert ctx, lib.gpsr_last_error()
     try:
         assert lib.gpsr_ctx_workspace_bytes(ctx) >= lib.gpsr_fit_workspace_bytes(B, n, 8)
@@ -291,8 +291,43 @@ def test_context_workspace_and_flag_count():
         assert lib.gpsr_flag_count(flags_b.data_ptr(), B, st) == 2
     finally:
         lib.gpsr_destroy(ctx)
-    assert lib.gpsr_create(torch.cuda.current_device(), 0, n) is None   # bad size: NULL + error text
+    assert lib.gpsr_create(torch.cuda.current_device(), 0, n, 0) is None   # bad size: NULL + error text
     assert b"gpsr_create" in lib.gpsr_last_error()
+
+
+def test_context_workspace_runs_predict_pixels():
+    """A context created with max_m > 0 holds enough for gpsr_predict_pixels (any chunk); one created with
+    max_m = 0 is refused with "workspace too small" instead of being overrun."""
+    from super_resolution_amd import _lib, engine, ops
+    lib = _lib.load()
+    s, p, H, W = 2, 20, 44, 40
+    lr = natural_image(H, W, 31)
+    from oracle import cvops
+    tin, tst = to_dev(lr), to_dev(cvops.resize_cubic(lr, fx=s, fy=s))
+    rows, cols, _ = engine._geometry(H, W, s, p, 0.9)
+    tidx = engine.training_indices(p)
+    rows_d, cols_d, tidx_d = to_dev(np.asarray(rows, np.int32)), to_dev(np.asarray(cols, np.int32)), to_dev(tidx)
+    want, _, _ = ops.predict_pixels_fused(tin, tin, tst, s, p, rows_d, cols_d, tidx_d, ops.MATERN32, iters=5)
+    B, n, m = len(rows) * len(cols), (p - 2) ** 2, (p * s - 2) ** 2
+    st = torch.cuda.current_stream().cuda_stream
+    for max_m, chunk in ((m, 0), (m, 4), (0, 0)):
+        ctx = lib.gpsr_create(torch.cuda.current_device(), B, n, max_m)
+        assert ctx, lib.gpsr_last_error()
+        try:
+            out = torch.empty((H * s, W * s), dtype=torch.float64, device=tin.device)
+            flags = torch.empty(B, dtype=torch.int32, device=tin.device)
+            rc = lib.gpsr_predict_pixels(tin.data_ptr(), tin.data_ptr(), tst.data_ptr(), H, W, s, p, rows_d.data_ptr(),
+                                         len(rows), cols_d.data_ptr(), len(cols), tidx_d.data_ptr(), len(tidx),
+                                         ops.MATERN32, 0.0, 0.0, 5, 0.1, ops.AVERAGE, chunk, out.data_ptr(), None,
+                                         flags.data_ptr(), lib.gpsr_ctx_workspace(ctx), lib.gpsr_ctx_workspace_bytes(ctx), st)
+            if max_m == 0:
+                assert rc < 0 and b"workspace too small" in lib.gpsr_last_error()
+            else:
+                assert rc == 0, lib.gpsr_last_error()
+                assert lib.gpsr_flag_count(flags.data_ptr(), B, st) == 0
+                assert torch.equal(out, want)
+        finally:
+            lib.gpsr_destroy(ctx)
 
 
 @pytest.mark.parametrize("kid", [0, 1, 2, 3, 4])

@@ -81,7 +81,7 @@ def test_apply_for_channel_vs_oracle_independent(kid, s, H, W):
     lr = _lr_image(H, W, 11 * kid + s)
     o = osr.OracleGPRSR(s, kid, "GRAYSCALE", chain=False)
     want = o.apply_for_channel_float(lr)
-    g = GPRSR(s, _kernels()[kid], ColorSpace.GRAYSCALE)
+    g = GPRSR(s, _kernels()[kid], ColorSpace.GRAYSCALE, warm_start="independent")
     got = g.apply_for_channel_device([__import__("super_resolution_amd").ops.u8_to_unit(to_dev(lr))])[0].cpu().numpy()
     assert got.shape == want.shape == (H * s, W * s)
     assert np.abs(got - want).max() < 2e-3 / 255
@@ -126,10 +126,10 @@ def test_batch_of_images_equals_one_by_one():
     from super_resolution_amd.gprsr import GPRSR, ColorSpace
     from super_resolution_amd import kernels as K
     imgs = [_lr_image(44, 40, 1), _lr_image(40, 47, 2), _lr_image(52, 41, 3)]
-    g = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE)
+    g = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, warm_start="independent")
     together = g.apply_for_channel_batch(imgs)
     for im, t in zip(imgs, together):
-        assert np.array_equal(GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE).apply_for_channel(im), t)
+        assert np.array_equal(GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, warm_start="independent").apply_for_channel(im), t)
 
 
 def test_patch_handler_combine_on_gpu(golden_dir):
@@ -161,7 +161,7 @@ def test_set14_x3_matern52_parity(golden_dir):
     from super_resolution_amd import kernels as K
     data = _set14(golden_dir)
     assert len(data) >= 1
-    g = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE)
+    g = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start="independent")
     outs = g.apply_for_channel_batch([lr for _, lr, _, _ in data])
     dp, ds = [], []
     for (i, lr, hr, want), got in zip(data, outs):
@@ -185,7 +185,7 @@ def test_set14_x3_final_hypers_close_to_oracle(golden_dir):
     data = _set14(golden_dir)[:3]
     hyp = np.load(os.path.join(golden_dir, "set14_x3", "hypers_m52.npz"))
     for i, lr, _, _ in data:
-        g = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE)
+        g = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start="independent")
         g.apply_for_channel(lr)
         for phase, key in enumerate([f"p1_{i:03d}", f"p2_{i:03d}"]):
             got, want = g.stats.raw[phase].cpu().numpy(), hyp[key]
@@ -248,7 +248,7 @@ def test_non_default_options_vs_oracle():
         gprsr.PATCH_INTERPOLATION = PatchInterpolationMode.BILINEAR
         gprsr.STRIDE_PERCENTAGE = 0.7
         gprsr.LEARNING_RATE = 0.05
-        g = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE)
+        g = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, warm_start="independent")
         got = g.apply_for_channel_device([ops.u8_to_unit(to_dev(lr))])[0].cpu().numpy()
     finally:
         (gprsr.USE_ALL_PIXELS_FOR_TRAINING, gprsr.PATCH_INTERPOLATION, gprsr.STRIDE_PERCENTAGE,
@@ -320,7 +320,7 @@ def test_main_cli_end_to_end(golden_dir, tmp_path, capsys):
         shutil.copy(f"{src}/lr_{i:03d}.png", dst / f"img_{i:03d}_SRF_3_LR.png")
         shutil.copy(f"{src}/hr_{i:03d}.png", dst / f"img_{i:03d}_SRF_3_HR.png")
     rc = main.main(["--srf", "3", "--kernel", "matern52", "--color-space", "grayscale", "--images", "5,6",
-                    "--dataset-dir", str(tmp_path / "Set14"), "--batch-images", "--evaluate"])
+                    "--dataset-dir", str(tmp_path / "Set14"), "--batch-images", "--warm-start", "independent", "--evaluate"])
     assert rc == 0
     out = capsys.readouterr().out
     assert "Average - PSNR:" in out and "Upscaling 2 images took" in out

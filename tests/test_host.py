@@ -56,7 +56,7 @@ def test_empty_batches_are_no_ops():
     lib = _lib.load()
     N = None
     assert lib.gpsr_gather(N, N, N, 64, 64, 2, 20, N, 0, N, 18, N, N, N, N) == 0
-    assert lib.gpsr_init_hypers(N, 0, 324, 3, 0.0, 0.0, N, N, N) == 0
+    assert lib.gpsr_init_hypers(N, 0, 324, 3, 0.0, 0.0, N, 0, N, N) == 0
     assert lib.gpsr_covariance(N, 0, 324, 8, 3, N, N, N) == 0
     assert lib.gpsr_covariance_grad(N, 0, 324, 8, 3, N, N, N, N) == 0
     assert lib.gpsr_invert(N, 0, 336, N, N, N, 0, N) == 0
@@ -176,22 +176,34 @@ def test_shard_ranges_partition_the_patch_list():
 _WORKER = r'''
 import os, sys, numpy as np, torch, torch.distributed as dist
 sys.path.insert(0, {root!r})
-from super_resolution_amd.dist import shard_range, all_gather_rows, init_from_env
+from super_resolution_amd.dist import shard_range, exchange_rows, deal_chains, init_from_env
 rank, world, _ = init_from_env("gloo")
-B = 11
-full = torch.arange(B * 3, dtype=torch.float64).reshape(B, 3) * 1.5
-lo, hi = shard_range(B, rank, world)
-local = full[lo:hi].clone() + 0.0
-out = all_gather_rows(local, B, world)
-flags = all_gather_rows(torch.arange(lo, hi, dtype=torch.int32), B, world)
-assert torch.equal(out, full), (rank, out)
-assert torch.equal(flags, torch.arange(B, dtype=torch.int32))
+# contiguous slices (independent GPs), three tensors of different dtypes packed into ONE all-gather
+for B in (11, 1, 2):          # B = 1: rank 1 owns nothing and still takes part
+    full = torch.arange(B * 3, dtype=torch.float64).reshape(B, 3) * 1.5
+    raw = (torch.arange(B * 4, dtype=torch.float32).reshape(B, 4) - 7) / 3
+    owned = [np.arange(*shard_range(B, r, world), dtype=np.int64) for r in range(world)]
+    lo, hi = shard_range(B, rank, world)
+    out, r4, fl = exchange_rows([full[lo:hi].clone(), raw[lo:hi].clone(), torch.arange(lo, hi, dtype=torch.int32)],
+                                owned, B, rank, world)
+    assert torch.equal(out, full) and torch.equal(r4, raw), (rank, B, out)
+    assert torch.equal(fl, torch.arange(B, dtype=torch.int32))
+# chains dealt out whole: interleaved ownership
+lens = [5, 2, 7, 1]
+owner = deal_chains(lens, world)
+assert sorted(set(owner)) == list(range(world)) and owner[2] != owner[0]      # the two longest go to different ranks
+offs = np.concatenate([[0], np.cumsum(lens)])
+owned = [np.concatenate([np.arange(offs[j], offs[j + 1]) for j in range(len(lens)) if owner[j] == r]) for r in range(world)]
+B = int(offs[-1])
+full = torch.arange(B * 2, dtype=torch.float64).reshape(B, 2)
+(out,) = exchange_rows([full[torch.as_tensor(owned[rank])]], owned, B, rank, world)
+assert torch.equal(out, full)
 dist.barrier()
 sys.stdout.write("rank%dok\n" % rank); sys.stdout.flush()
 '''
 
 
-def test_all_gather_rows_world2_gloo(tmp_path):
+def test_exchange_rows_world2_gloo(tmp_path):
     script = tmp_path / "w.py"
     script.write_text(_WORKER.format(root=ROOT))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29611", OMP_NUM_THREADS="1")
@@ -225,10 +237,23 @@ def fake_combine(pred, tst, H, W, s, p, rows, cols, mode, clip=True):
     return torch.tensor(np.clip(P.combine(ups, locs, (H, W), p, mode), 0, 1))
 ops.gather, ops.combine = fake_gather, fake_combine
 class FakeGP:
-    def fit_predict(self, X, y, Xs, chain_kernel=None):
+    def fit_predict(self, X, y, Xs):
         pred = Xs.mean(-1) * 0.5 + y.mean(-1, keepdim=True) * 0.5
         raw = torch.stack([y.mean(-1), y.std(-1), X.mean((1, 2)), X.amax((1, 2))], 1).float()
         return pred, raw, torch.zeros(X.shape[0], dtype=torch.int32)
+    def fit_predict_chains(self, X, y, Xs, lens, carry):
+        # a serial recurrence along each chain, so a wrong order / wrong owner shows
+        pred, raw, fl = self.fit_predict(X, y, Xs)
+        o = 0
+        for j, L in enumerate(lens):
+            c = carry[j, 2].double()
+            for k in range(L):
+                c = 0.5 * c + y[o + k].mean()
+                pred[o + k] += c
+                raw[o + k, 2] = c.float()
+            carry[j, 2] = c.float()
+            o += L
+        return pred, raw, fl
 rng = np.random.default_rng(0)
 jobs = []
 for (H, W) in [(47, 53), (52, 36)]:
@@ -241,6 +266,20 @@ if rank == 0:
     for o, r in zip(outs, ref):
         assert torch.equal(o, r)
     assert st.raw[0].shape == (24, 4)
+# warm-start chains: whole jobs per rank, carries exchanged
+c1 = torch.tensor([[0., 0., 0.25, 0.], [0., 0., -1.0, 0.]])
+c2 = c1.clone()
+outs = engine.predict_pixels_batch(jobs, 2, 20, FakeGP(), chain_carry=c1, shard=(rank, world))
+ref = engine.predict_pixels_batch(jobs, 2, 20, FakeGP(), chain_carry=c2, shard=None)
+for o, r in zip(outs, ref):
+    assert torch.equal(o, r)
+assert torch.equal(c1, c2) and not torch.equal(c1[:, 2], torch.tensor([0.25, -1.0]))
+# fewer patches than ranks: one 20x20 image has 4 (duplicate) patches; 1 job as a chain -> rank 1 owns nothing
+small = [(torch.tensor(rng.random((20, 20))), torch.tensor(rng.random((20, 20))), torch.tensor(rng.random((40, 40))))]
+c3 = torch.zeros((1, 4))
+o1 = engine.predict_pixels_batch(small, 2, 20, FakeGP(), chain_carry=c3, shard=(rank, world))
+o2 = engine.predict_pixels_batch(small, 2, 20, FakeGP(), chain_carry=torch.zeros((1, 4)), shard=None)
+assert torch.equal(o1[0], o2[0])
 dist.barrier()
 sys.stdout.write("rank%dok\n" % rank); sys.stdout.flush()
 '''

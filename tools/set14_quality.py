@@ -25,7 +25,7 @@ def main():
     lrs = [read_gray(os.path.join(d, f"lr_{i:03d}.png")) for i in ids]
     hrs = [read_gray(os.path.join(d, f"hr_{i:03d}.png")) for i in ids]
     ors = [read_gray(os.path.join(d, f"oracle_m52_{i:03d}.png")) for i in ids]
-    outs = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE).apply_for_channel_batch(lrs)
+    outs = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start="independent").apply_for_channel_batch(lrs)
     bic = [imgproc.resize_cubic_u8(lr, fx=3, fy=3) for lr in lrs]
     c = 3
     rows = []
