@@ -154,6 +154,23 @@ int gpsr_fit(const double* X, const double* y, int B, int n, int d, int kernel_i
              void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * gpsr_fit that allocates nothing.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  Same arguments and results (bit-identical) as gpsr_fit minus the workspace: the scratch
+ * (covariance matrices, panels, pivot factors, statistics, Adam moments) lives in a file-scope __device__
+ * array of gpsr_noalloc_scratch_bytes() = 64 MiB that every GPU the library runs on holds until the process
+ * ends.  Limit: gpsr_fit_workspace_bytes-like need of the batch <= 64 MiB, i.e. about 9 GPs of n = 784, 33 of
+ * n = 324, 130 of n <= 112; larger batches are rejected (<0, text in gpsr_last_error()).  The call makes no
+ * hipMalloc / hipFree (no allocating routine at all: its launch list lives on the stack), never runs
+ * dual-stream, and is asynchronous on `stream`.  All calls on one GPU share that GPU's array: calls that
+ * overlap on one GPU (two streams, two threads) race -- order them on one stream.
+ */
+size_t gpsr_noalloc_scratch_bytes(void);
+int gpsr_fit_noalloc(const double* X, const double* y, int B, int n, int d, int kernel_id,
+                     float* raw, int iters, float lr, double* alpha, double* loss, int32_t* flags,
+                     void* stream);
+
+/*
  * Opt-in: gpsr_fit runs a batch of >= 256 GPs as two half-batches on two streams (the caller's and an
  * internal one, forked from and joined to it with events), which fills part of the machine that the small
  * latency-bound launches of one batch leave idle (+5 % throughput on Set14 x3).  Results are bit-identical.

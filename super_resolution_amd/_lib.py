@@ -36,6 +36,9 @@ SIGNATURES = {
     "gpsr_fit_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gpsr_fit": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float,
                          c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gpsr_noalloc_scratch_bytes": (c_size_t, []),
+    "gpsr_fit_noalloc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float,
+                                 c_void_p, c_void_p, c_void_p, c_void_p]),
     "gpsr_set_dual_stream": (c_int, [c_int]),
     "gpsr_loss_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),

@@ -546,6 +546,102 @@ extern "C" int gpsr_fit(const double* X, const double* y, int B, int n, int d, i
   return run_dual(ops, a, b, c, ss);
 }
 
+// ---------------------------------------------------------------- fit without any allocation
+// For callers that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses
+// that forbid it): gpsr_fit with its workspace in a file-scope __device__ array instead of a caller / context
+// allocation.  Each GPU the library runs on holds its own copy of the array, at its own address, until the
+// process ends; the host-side name `g_noalloc_scratch` is only a handle for hipGetSymbolAddress -- the device
+// address it returns (per device, looked up once with that device current) is what kernels and memsets get.
+#define GPSR_NOALLOC_BYTES ((size_t)64 << 20)
+static __device__ __align__(256) unsigned char g_noalloc_scratch[GPSR_NOALLOC_BYTES];
+static void* g_noalloc_ptr[64] = {};
+#include <mutex>
+static std::mutex g_noalloc_mu;
+
+static int noalloc_scratch(void** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  if (dev < 0 || dev >= 64) return arg_fail("device index out of range for the static scratch table");
+  std::lock_guard<std::mutex> lock(g_noalloc_mu);
+  if (!g_noalloc_ptr[dev]) {
+    void* p = nullptr;
+    e = hipGetSymbolAddress(&p, HIP_SYMBOL(g_noalloc_scratch));
+    if (e != hipSuccess || !p) return hip_fail(e, "hipGetSymbolAddress(static scratch)");
+    g_noalloc_ptr[dev] = p;
+  }
+  *out = g_noalloc_ptr[dev];
+  return 0;
+}
+
+extern "C" size_t gpsr_noalloc_scratch_bytes(void) { return GPSR_NOALLOC_BYTES; }
+
+extern "C" int gpsr_fit_noalloc(const double* X, const double* y, int B, int n, int d, int kernel_id, float* raw,
+                                int iters, float lr, double* alpha, double* loss, int32_t* flags, void* stream) {
+  if (B <= 0) return 0;
+  if (!X || !y) return arg_fail("null pointer");
+  if (n < 2 || d < 1 || d > 64 || kernel_id < 0 || kernel_id > 4) return arg_fail("fit shape / kernel_id");
+  const int N = gpsr_padded_n(n), nblk = N / NB;
+  if (N > 16 * NB) return arg_fail("n too large (max 1792)");
+  if (!raw || !alpha || !flags || iters < 0) return arg_fail("fit outputs");
+  const size_t need = fit_ws_bytes1(B, N);
+  if (need > GPSR_NOALLOC_BYTES) {
+    snprintf(g_err, sizeof(g_err), "gpsr_fit_noalloc: %d GPs of n=%d need %zu bytes of scratch, the static array holds %zu "
+             "(use gpsr_fit with a caller workspace)", B, n, need, (size_t)GPSR_NOALLOC_BYTES);
+    return -1;
+  }
+  void* ws = nullptr;
+  int rc = noalloc_scratch(&ws);
+  if (rc) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
+  if (e != hipSuccess) return hip_fail(e, "memset flags");
+  Batch a = {};
+  a.B = B; a.X = X; a.y = y; a.raw = raw; a.alpha = alpha; a.loss = loss; a.flags = flags; a.st = st;
+  a.w = fit_ws_carve((char*)ws, B, N);
+  // the array keeps the last call's contents: the Adam moments must start at zero (everything else the
+  // kernels read is written earlier in the same call: A by k_build, logdet by k_build, panels by k_panel ...)
+  e = hipMemsetAsync(a.w.m1, 0, 2 * align256((size_t)B * 16), st);
+  if (e != hipSuccess) return hip_fail(e, "memset adam state");
+  FitShape c = {n, N, d, kernel_id, lr, nblk > 1};
+  // the launch list of ONE evaluation on the stack (no heap): <= 1 + 6*(nblk/2) + 3*2 + 2 entries
+  Op ops[64];
+  int nops = 0;
+  {
+    const int npairs = (g_pair_steps && nblk >= 3) ? (nblk - 1 - (nblk % 2 == 0 ? 1 : 0)) / 2 : 0;
+    ops[nops++] = {OP_BUILD, 0, 0, 0, true};
+    int k = 0;
+    for (int mth = 0; mth < npairs; ++mth, k += 2) {
+      ops[nops++] = {OP_PIVOT, k, 0, 0, false};
+      ops[nops++] = {OP_PANEL, k, 0, 0, false};
+      ops[nops++] = {OP_UPD_SEL, k, 0, 0, false};
+      ops[nops++] = {OP_PIVOT, k + 1, 1, 0, false};
+      ops[nops++] = {OP_PANEL, k + 1, 1, 0, false};
+      ops[nops++] = {OP_UPD2, k, 0, 0, true};
+    }
+    for (; k < nblk; ++k) {
+      ops[nops++] = {OP_PIVOT, k, 0, 0, false};
+      if (nblk > 1) {
+        ops[nops++] = {OP_PANEL, k, 0, 0, false};
+        ops[nops++] = {OP_UPD, k, 0, (k == nblk - 1) ? 1 : 0, true};
+      }
+    }
+    ops[nops++] = {OP_GRAD1, 0, 0, 0, false};
+  }
+  if ((rc = ensure_lds_attrs())) return rc;
+  const Op grad2 = {OP_GRAD2, 0, 0, 0, true};
+  for (int it = 1; it <= iters + 1; ++it) {
+    for (int i = 0; i < nops; ++i)
+      if ((rc = launch_op(ops[i], a, c))) return rc;
+    if (it <= iters) {
+      if ((rc = launch_op(grad2, a, c))) return rc;
+      const Op adam = {OP_ADAM, 0, 0, it, false};
+      if ((rc = launch_op(adam, a, c))) return rc;
+    }
+  }
+  return 0;
+}
+
 extern "C" int gpsr_loss_grad(const double* X, const double* y, int B, int n, int d, int kernel_id,
                               const float* raw, double* loss, float* grad, int32_t* flags, void* workspace,
                               size_t workspace_bytes, void* stream) {
