@@ -1,35 +1,39 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the batched SRGPR engine.
 
-Metric (BASELINE.json): output megapixels / second of SR x3 with the Matern-5/2
-kernel.  Workload at N=1 = BASELINE.json configs[1]: the full Set14 x3 set
-(14 LR images of the Set14 image_SRF_3 shapes, GRAYSCALE, 633 patches, 1266 GP
-fits of n=784, m=7744 each, 3.2066 output Mpx) -- synthetic images of exactly
-those shapes (the reference's PNGs do not travel to the GPU box).
+Metric (BASELINE.json): output megapixels / second of SR x3 with the Matern-5/2 kernel (+ PSNR parity).
+Workload at N=1 = BASELINE.json configs[1]: the full Set14 x3 set -- the 14 LR images of
+Set14/image_SRF_3 as grey PNG fixtures (tests/golden/set14_x3/lr_*.png; the reference's files do not travel to
+the GPU box), GRAYSCALE, 633 patches, 1266 GP fits of n=784, m=7744 each, 3.2066 output Mpx.
 
-A "step" = one pass of GPRSR.apply_for_channel over the whole batch (both
-phases: gather -> 50-step Adam fit -> predictive mean -> recombination, plus
-the bicubic / blur / decimation stages between them), inputs resident in HBM as
-float64 images when the clock starts, uint8 HR images in HBM when it stops.
+A "step" = one pass of GPRSR.apply_for_channel over the whole batch (both phases: gather -> 50-step Adam fit
+-> predictive mean -> recombination, plus the bicubic / blur / decimation stages between them), inputs resident
+in HBM as float64 images when the clock starts, uint8 HR images in HBM when it stops.
 
-N > 1 (weak scaling, default): the batch is N copies of the workload (different seeds);
-the global patch list is sharded over the ranks (super_resolution_amd/dist.py)
-and the predicted patches are all-gathered over RCCL; value = all output
-megapixels / max-over-ranks time.  --scaling strong shards ONE copy instead
-(BASELINE config 4: --workload 4kx2 --scaling strong at 1/2/4/8 GPUs).
+--warm-start independent (default: the north star's batched engine, every patch from the initial values),
+chain_per_image (the reference's warm-start chain, every image as the first image of a fresh reference process;
+the 14 chains advance together) or chain (the literal reference process: one chain through all images, serial).
+The `parity` object compares this run's outputs with the committed CPU-oracle outputs OF THE SAME MODE
+(tests/golden/set14_x3/oracle_m52_*.png / oracle_m52_chain_*.png) with the HIP metric kernels.
+
+--gpus N > 1: bench.py starts its N ranks itself (one process per GPU, RCCL), unless it already runs under
+torch.distributed.run (RANK set).  weak scaling (default for set14x3): N copies of the workload; strong (default
+for 4kx2 = BASELINE config 4): one copy sharded.  value = all output megapixels / max-over-ranks time.
 
 Prints ONE JSON line on rank 0 (contract in the task statement) with
-  roofline     : the dominant kernel (k_update2, f64 MFMA tile products), HIP-event timed
+  roofline     : the dominant kernel (k_update2, f64 MFMA tile products), HIP-event timed, + whole_step_frac
   cpu_baseline : the CPU oracle (torch f64 restatement of the GPyTorch loop) on a bounded sample
+  parity       : max |diff| in grey levels, dPSNR / dSSIM against the committed goldens of the mode
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
@@ -39,6 +43,7 @@ SET14_X3_LR_SHAPES = [(160, 166), (192, 240), (170, 170), (96, 117), (120, 83), 
                       (96, 117), (170, 170), (170, 170), (170, 256), (170, 170), (218, 176), (130, 195)]
 FP64_MFMA_PEAK_TFLOPS = 78.6   # MI355X FP64 matrix peak (AMD spec; the microarch guide lists no f64 row)
 NB = 112
+GOLDEN = os.path.join(ROOT, "tests", "golden", "set14_x3")
 
 
 def synthetic_lr(H, W, seed):
@@ -55,9 +60,21 @@ def synthetic_lr(H, W, seed):
     return np.clip(np.rint(img), 0, 255).astype(np.uint8)
 
 
-def workload(name, copies):
+def _png(name):
+    from PIL import Image
+    return np.array(Image.open(os.path.join(GOLDEN, name)))
+
+
+def workload(name, copies, synthetic=False):
+    """-> (list of uint8 LR images, scale factor, data description)."""
     if name == "set14x3":
-        shapes, s = SET14_X3_LR_SHAPES, 3
+        s = 3
+        real = (not synthetic) and all(os.path.exists(os.path.join(GOLDEN, f"lr_{i:03d}.png")) for i in range(1, 15))
+        if real:
+            base = [_png(f"lr_{i:03d}.png") for i in range(1, 15)]
+            assert [b.shape for b in base] == SET14_X3_LR_SHAPES
+            return base * copies, s, "Set14 x3 LR images (grey PNG fixtures tests/golden/set14_x3/lr_*.png)"
+        shapes = SET14_X3_LR_SHAPES
     elif name == "4kx2":
         shapes, s = [(2160, 3840)], 2
     elif name == "tiny":
@@ -68,7 +85,7 @@ def workload(name, copies):
     for c in range(copies):
         for i, (H, W) in enumerate(shapes):
             imgs.append(synthetic_lr(H, W, 1234 + 100 * c + i))
-    return imgs, s
+    return imgs, s, "synthetic"
 
 
 def patch_count(shape, s):
@@ -80,6 +97,7 @@ def patch_count(shape, s):
 def cpu_baseline(kernel_id, s, seconds_budget=20.0):
     """Oracle (CPU restatement of the reference's per-patch GPyTorch loop) timed on a
     bounded sample of the same workload: whole patch fits (n=(10s-2)^2, m=(10s^2-2)^2)."""
+    import torch
     from oracle import gp as ogp, patches as opatch, cvops
     cores = int(os.environ.get("OMP_NUM_THREADS", "0")) or min(16, os.cpu_count() or 1)
     torch.set_num_threads(cores)
@@ -99,60 +117,131 @@ def cpu_baseline(kernel_id, s, seconds_budget=20.0):
     return dt / done, done, cores
 
 
-def pmc_traffic(kernel, workload, B_local, N):
+def pmc_traffic(kernel, B_local, N):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 --pmc passes (FETCH_SIZE x2 per the gfx950
-    correction of MI355X_MICROARCH.md, + WRITE_SIZE), which were taken on 633 GPs of order 784 = this bench's
-    default shape.  Counters cannot be read from inside this process: None for any other shape or if the
-    summary is absent."""
-    path = os.path.join(ROOT, "profiles", "r01_pmc_invert_633x784.json")
-    if workload != "set14x3" or B_local != 633 or N != 784 or not os.path.exists(path):
-        return None
-    try:
-        with open(path) as f:
-            return round(json.load(f)["hbm_bytes_per_launch"][kernel]["traffic_corrected"])
-    except (KeyError, ValueError):
-        return None
+    correction of MI355X_MICROARCH.md, + WRITE_SIZE), taken on B_local GPs of order N.  Counters cannot be
+    read from inside this process: None for a shape without a committed summary."""
+    for rnd in ("r02", "r01"):
+        path = os.path.join(ROOT, "profiles", f"{rnd}_pmc_invert_{B_local}x{N}.json")
+        if os.path.exists(path):
+            try:
+                with open(path) as f:
+                    return round(json.load(f)["hbm_bytes_per_launch"][kernel]["traffic_corrected"]), os.path.relpath(path, ROOT)
+            except (KeyError, ValueError):
+                pass
+    return None, None
 
 
-def main():
+def fit_flops(n, m, iters=50):
+    """algorithmic flops of one patch fit (potrf + inverse for the trace + kernel/derivative
+    evaluations and solves per Adam iteration, final factorisation + predictive mean)."""
+    f_iter = n ** 3 / 3 + 2 * n ** 3 / 3 + 38 * n * n
+    return iters * f_iter + n ** 3 / 3 + 38 * m * n
+
+
+# ------------------------------------------------------------------ rank launcher
+def launch_ranks(n, argv, script=None, extra_env=None, timeout=None):
+    """Start n ranks of `script` (default: this file) as child processes, one per GPU: RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_ADDR / MASTER_PORT in the environment, backend chosen by the child (nccl = RCCL on GPUs).
+    The parent touches no GPU; it relays rank 0's stdout (the JSON line) and returns non-zero if any rank fails
+    (the others are terminated).  -> (returncode, rank-0 stdout)."""
+    script = script or os.path.abspath(__file__)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        env.update(extra_env or {})
+        procs.append(subprocess.Popen([sys.executable, "-u", script] + list(argv), env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    t0 = time.time()
+    rc = 0
+    alive = set(range(n))
+    while alive:
+        for r in list(alive):
+            code = procs[r].poll()
+            if code is None:
+                continue
+            alive.discard(r)
+            if code != 0 and rc == 0:
+                rc = code if code > 0 else 1
+                sys.stderr.write(f"bench.py: rank {r} exited with {code}; stopping the other ranks\n")
+                for q in alive:
+                    procs[q].terminate()
+        if timeout is not None and time.time() - t0 > timeout and alive:
+            rc = rc or 124
+            for q in alive:
+                procs[q].kill()
+        time.sleep(0.05)
+    out = procs[0].stdout.read() if procs[0].stdout else ""
+    return rc, out
+
+
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--workload", default="set14x3")
     ap.add_argument("--kernel", default="matern52")
+    ap.add_argument("--warm-start", default="independent", choices=("independent", "chain_per_image", "chain"))
+    ap.add_argument("--synthetic", action="store_true", help="synthetic images of the Set14 shapes instead of the fixtures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
-                    help="N > 1: weak = N copies of the workload (default, the driver's scaling run); strong = ONE copy "
-                         "whose patches are sharded over the N ranks (BASELINE config 4: one 4K image at 1/2/4/8 GPUs)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
+                    help="N > 1: weak = N copies of the workload (default for set14x3); strong = ONE copy whose patches "
+                         "are sharded over the N ranks (default for 4kx2 = BASELINE config 4: one 4K image at 1/2/4/8 GPUs)")
     ap.add_argument("--max-workspace-gb", type=float, default=48.0)
     ap.add_argument("--dual-stream", action="store_true",
                     help="gpsr_set_dual_stream(1): two half-batches on two streams (+5 %% throughput; per-launch "
                          "durations then overlap, so the roofline object describes launches that share the GPU)")
-    a = ap.parse_args()
+    a = ap.parse_args(argv)
+    if a.scaling is None:
+        a.scaling = "strong" if a.workload == "4kx2" else "weak"
+
+    import torch
+    if a.gpus > 1 and "RANK" not in os.environ:
+        # launcher: start the ranks before anything touches a GPU (device_count does not initialise it)
+        have = torch.cuda.device_count()
+        if have < a.gpus and "GPSR_LOCAL_DEVICE" not in os.environ:
+            raise SystemExit(f"bench.py --gpus {a.gpus}: only {have} GPU(s) visible -- refusing to report a "
+                             f"{a.gpus}-GPU number from fewer devices")
+        rc, out = launch_ranks(a.gpus, argv)
+        sys.stdout.write(out)
+        sys.stdout.flush()
+        if rc == 0 and '"n_gpus": %d' % a.gpus not in out:
+            sys.stderr.write("bench.py: rank 0 printed no JSON line for the requested rank count\n")
+            rc = 1
+        return rc
 
     from super_resolution_amd import dist as gdist
     rank, world, local = gdist.init_from_env()
-    if world != a.gpus and world > 1:
+    if world != a.gpus:
         raise SystemExit(f"--gpus {a.gpus} but WORLD_SIZE={world}")
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
 
     from super_resolution_amd import kernels as K, ops
     from super_resolution_amd.gprsr import GPRSR, ColorSpace
+    kname = "matern32" if (a.workload == "4kx2" and a.kernel == "matern52") else a.kernel   # BASELINE.json config 4
     kern = {"matern52": K.matern52_kernel, "matern32": K.matern32_kernel, "rbf": K.rbf_kernel,
-            "exponential": K.exponential_kernel}[a.kernel]
-    if a.workload == "4kx2" and a.kernel == "matern52":
-        kern = K.matern32_kernel  # BASELINE.json config 4
+            "exponential": K.exponential_kernel}[kname]
     ops.set_dual_stream(a.dual_stream)
-    imgs_u8, s = workload(a.workload, world if a.scaling == "weak" else 1)
+    copies = world if a.scaling == "weak" else 1
+    imgs_u8, s, data_desc = workload(a.workload, copies, a.synthetic)
+    n_base = len(imgs_u8) // copies
     out_px = sum(im.shape[0] * s * im.shape[1] * s for im in imgs_u8)
     n_patches = sum(patch_count(im.shape, s) for im in imgs_u8)
-    g = GPRSR(s, kern, ColorSpace.GRAYSCALE, warm_start="independent", shard=(rank, world) if world > 1 else None,
+    g = GPRSR(s, kern, ColorSpace.GRAYSCALE, warm_start=a.warm_start, shard=(rank, world) if world > 1 else None,
               max_workspace_bytes=int(a.max_workspace_gb * (1 << 30)))
     imgs = [ops.u8_to_unit(torch.as_tensor(im).to(dev)) for im in imgs_u8]
 
     def step():
+        if a.warm_start == "chain":
+            kern.reset()     # every step = one fresh reference process over the image list
         outs = g.apply_for_channel_device(imgs)
         return [ops.unit_to_u8(o, 255.0) for o in outs]
 
@@ -166,24 +255,51 @@ def main():
         step()
     barrier()
     if rank == 0:
-        ops.profile_begin(1 << 16)
+        ops.profile_begin(1 << 18)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         outs = step()
     barrier()
     dt = time.perf_counter() - t0
     prof = ops.profile_end() if rank == 0 else None
+    ranks_seen, backend = 1, None
     if world > 1:
-        t = torch.tensor([dt], dtype=torch.float64,
-                         device=dev if torch.distributed.get_backend() == "nccl" else "cpu")   # gloo: one-GPU rehearsal
+        backend = torch.distributed.get_backend()
+        ranks_seen = torch.distributed.get_world_size()
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")   # gloo: one-GPU rehearsal
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         dt = float(t.item())
     flags_bad = int(sum(int(f.sum()) for f in g.stats.flags))
+    if a.warm_start == "chain":
+        kern.reset()
 
     if rank != 0:
-        return
+        return 0
     ms_per_step = dt / a.steps * 1e3
     value = out_px / 1e6 / (dt / a.steps)
+
+    # ---- parity against the committed oracle outputs of this mode (HIP metric kernels; Set14 fixtures only)
+    parity = None
+    gold_tag = {"independent": "oracle_m52", "chain_per_image": "oracle_m52_chain"}.get(a.warm_start)
+    if (a.workload == "set14x3" and kname == "matern52" and data_desc != "synthetic" and gold_tag
+            and all(os.path.exists(os.path.join(GOLDEN, f"{gold_tag}_{i:03d}.png")) for i in range(1, n_base + 1))):
+        maxd, ident, npx_all, dps, dss, ps, pg = 0, 0, 0, [], [], [], []
+        for i in range(n_base):
+            gold = torch.as_tensor(_png(f"{gold_tag}_{i + 1:03d}.png")).to(dev)
+            hr = torch.as_tensor(_png(f"hr_{i + 1:03d}.png")).to(dev)
+            d = (outs[i].to(torch.int16) - gold.to(torch.int16)).abs()
+            maxd = max(maxd, int(d.max()))
+            ident += int((d == 0).sum())
+            npx_all += d.numel()
+            mo, mg = ops.metrics(hr, outs[i], s).cpu().numpy(), ops.metrics(hr, gold, s).cpu().numpy()
+            dps.append(mo[0] - mg[0]); dss.append(mo[1] - mg[1]); ps.append(mo[0]); pg.append(mg[0])
+        parity = {"golden": f"tests/golden/set14_x3/{gold_tag}_*.png (CPU oracle, same warm-start mode)",
+                  "max_abs_diff_grey_levels": maxd, "identical_pixel_frac": round(ident / npx_all, 6),
+                  "mean_psnr_db": round(float(np.mean(ps)), 4), "mean_psnr_db_golden": round(float(np.mean(pg)), 4),
+                  "max_abs_dpsnr_db": round(float(np.max(np.abs(dps))), 5),
+                  "max_abs_dssim": round(float(np.max(np.abs(dss))), 6),
+                  "bar": "<= 1 grey level, 0.01 dB, 0.001 (north star)",
+                  "ok": bool(maxd <= 1 and np.max(np.abs(dps)) <= 0.01 and np.max(np.abs(dss)) <= 0.001)}
 
     # roofline of the dominant kernel.  Pivots are taken two at a time: k_update2 applies both rank-112 updates of
     # a pair in one pass over A (batched 112x112x224 f64 MFMA tile products).  Algorithmic flops of one launch, per
@@ -192,30 +308,34 @@ def main():
     # 112^3, the triangular pivot-column product of the second step (N-112)*112^2.  (Matrices of fewer than 3
     # blocks have no pair: then k_update, (N-112)^2*112 + (N-112)*112^2.)
     n = (10 * s - 2) ** 2
+    m = (10 * s * s - 2) ** 2
     N = -(-n // NB) * NB
-    B_local = -(-n_patches // world)
-    # A launch covers the whole local batch unless the engine cut it into workspace-sized chunks (4kx2) or the
-    # dual-stream scheduler into halves: GPs per launch = local batch x launches a whole-batch run would make / launches
-    # made.  Whole-batch launches per step: 2 phases x 51 evaluations (50 Adam steps + the final one) x passes per sweep.
     nblk = N // NB
     if prof.get("update2", (0, 0.0))[0]:
         kname_dom, (cnt, ms) = "k_update2", prof["update2"]
         R = N - 2 * NB
         flops_gp = R * R * 2 * NB + 3 * R * NB * NB + NB ** 3 + (N - NB) * NB * NB
-        passes = (nblk - 1) // 2 if nblk % 2 else (nblk - 2) // 2
     else:
         kname_dom, (cnt, ms) = "k_update", prof["update"]
         flops_gp = (N - NB) ** 2 * NB + (N - NB) * NB * NB
-        passes = nblk
+    # GPs per launch: every GP of rank 0's share passes through the kernel `passes` times per evaluation, 2 phases x
+    # 51 evaluations per step, however the engine cut the batch (workspace chunks, chain links, dual-stream halves)
+    passes = ((nblk - 1) // 2 if nblk % 2 else (nblk - 2) // 2) if kname_dom == "k_update2" else nblk
+    B_local = -(-n_patches // world)
     gps_per_launch = B_local * (2 * (g.iters + 1) * passes * a.steps) / cnt if cnt else 0.0
     flops_launch = int(gps_per_launch * flops_gp)
     avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
     achieved = flops_launch / avg_s / 1e12 if cnt else float("nan")
     kernel_ms = {k: round(v[1] / a.steps, 3) for k, v in prof.items()}
+    traffic, traffic_src = pmc_traffic(kname_dom, int(round(gps_per_launch)), N)
+    whole = (n_patches / world) * 2 * fit_flops(n, m, g.iters) / (dt / a.steps) / 1e12    # per GPU
     roofline = {"kernel": kname_dom, "bound": "mfma", "achieved": round(achieved, 3),
                 "peak": FP64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / FP64_MFMA_PEAK_TFLOPS, 4),
-                "traffic": pmc_traffic(kname_dom, a.workload, int(round(gps_per_launch)), N),
-                "traffic_note": "HBM bytes per launch, profiles/r01_pmc_invert_633x784.json (separate rocprofv3 --pmc passes)",
+                "traffic": traffic,
+                "traffic_note": f"HBM bytes per launch, {traffic_src} (separate rocprofv3 --pmc passes)" if traffic_src
+                else "no committed PMC summary for this shape",
+                "whole_step_frac": round(whole / FP64_MFMA_PEAK_TFLOPS, 4),
+                "whole_step_note": "SURVEY 8(d) algorithmic flops of all fits of one GPU / step time / FP64 peak",
                 "launches_per_step": cnt // max(1, a.steps), "gps_per_launch": round(gps_per_launch, 1),
                 "avg_launch_ms": round(avg_s * 1e3, 4),
                 "flops_per_launch": flops_launch, "kernel_ms_per_step": kernel_ms}
@@ -223,31 +343,34 @@ def main():
     cpu = None
     if not a.no_cpu_baseline and world == 1:   # reported at N=1 only (rank 0 would stall the other ranks' exit)
         sec_per_fit, nfit, cores = cpu_baseline(g._gp.kernel_id, s)
-        copies = world if a.scaling == "weak" else 1
         fits = 2 * n_patches // copies  # per copy of the workload
         cpu_val = (out_px / copies) / 1e6 / (sec_per_fit * fits)
         cpu = {"value": round(cpu_val, 6), "unit": "output Mpx/s", "cores": cores, "kind": "port",
-               "sample": f"{nfit} whole patch fits (n={n}, 50 Adam steps + predictive mean, m={(10 * s * s - 2) ** 2}) "
+               "sample": f"{nfit} whole patch fits (n={n}, 50 Adam steps + predictive mean, m={m}) "
                          f"of the oracle's torch-f64 per-patch loop, {sec_per_fit:.2f} s/fit, extrapolated "
-                         f"linearly to the workload's {fits} fits (patch gather/recombination not counted)"}
+                         f"linearly to the workload's {fits} fits (patch gather/recombination not counted; the "
+                         f"warm-start mode does not change the cost of a fit)"}
 
-    kname = "matern32" if (a.workload == "4kx2" and a.kernel == "matern52") else a.kernel
-    line = {"metric": "output megapixels/sec (SR x3, Matern-5/2)" if (a.workload == "set14x3" and kname == "matern52")
+    headline = a.workload == "set14x3" and kname == "matern52"
+    line = {"metric": "output megapixels/sec (SR x3, Matern-5/2)" if headline
             else f"output megapixels/sec ({a.workload}, {kname})",
             "value": round(value, 4), "unit": "Mpx/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup,
             "ms_per_step": round(ms_per_step, 2), "higher_is_better": True, "scaling": a.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": data_desc,
             "config": {"workload": f"{a.workload}: {len(imgs_u8)} images, {n_patches} patches, "
                                    f"{2 * n_patches} GP fits (n={n}), {out_px / 1e6:.4f} output Mpx",
                        "kernel": kname,
-                       "color": "GRAYSCALE", "warm_start": "independent", "dual_stream": bool(a.dual_stream),
-                       "parallelism": f"patch-sharded x{world}"},
+                       "color": "GRAYSCALE", "warm_start": a.warm_start, "dual_stream": bool(a.dual_stream),
+                       "parallelism": (f"patch-sharded x{world}" if a.warm_start == "independent"
+                                       else f"whole chains dealt to {world} rank(s)"),
+                       "ranks_in_process_group": ranks_seen, "backend": backend},
             "nonpositive_pivot_flags": flags_bad,
-            "roofline": roofline, "cpu_baseline": cpu}
+            "parity": parity, "roofline": roofline, "cpu_baseline": cpu}
     if cpu:
         line["speedup_vs_cpu_baseline"] = round(value / cpu["value"], 1)
     print(json.dumps(line), flush=True)
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

@@ -117,14 +117,16 @@ class AGPRSuperResolution:
         return self._weights
 
     def upscale(self, image: np.ndarray) -> np.ndarray:
+        # the colour image goes to the GPU once: conversion, chroma resize and merge are HIP kernels (agpr.py:148-158)
+        bgr = torch.as_tensor(np.ascontiguousarray(image, dtype=np.uint8)).to(_device())
         if COLOR_SPACE == ColorSpace.YCRCB:
-            y, cr, cb = imgproc.bgr2ycrcb(image)
-            y = self.upscale_channel(y).astype(np.uint8)
-            cr = imgproc.resize_cubic_u8(cr, dsize=(y.shape[1], y.shape[0]))
-            cb = imgproc.resize_cubic_u8(cb, dsize=(y.shape[1], y.shape[0]))
-            return imgproc.ycrcb2bgr(y, cr, cb)
+            y, cr, cb = ops.bgr2ycrcb(bgr)
+            y = ops.unit_to_u8(self.upscale_channel_device(ops.u8_to_unit(y)), 1.0)     # .astype(np.uint8), agpr.py:151
+            cr = imgproc.resize_cubic_u8_dev(cr, dsize=(y.shape[1], y.shape[0]))
+            cb = imgproc.resize_cubic_u8_dev(cb, dsize=(y.shape[1], y.shape[0]))
+            return ops.ycrcb2bgr(y, cr, cb).cpu().numpy()
         elif COLOR_SPACE == ColorSpace.GRAYSCALE:
-            return self.upscale_channel(imgproc.bgr2gray(image))
+            return self.upscale_channel_device(ops.u8_to_unit(ops.bgr2gray(bgr))).cpu().numpy()
 
     def upscale_channel(self, image: np.ndarray) -> np.ndarray:
         return self.upscale_channel_device(_to_dev(image / 255.)).cpu().numpy()

@@ -6,7 +6,9 @@ get_metrics / get_psnr / get_ssim / preprocess_image / evaluate_image /
 evaluate_method / evaluate.  PSNR and SSIM follow skimage.metrics
 (peak_signal_noise_ratio, structural_similarity with its defaults: 7x7 uniform
 window, sample covariance, K1=.01, K2=.03) on the grey image cropped by srf pixels.
-Host numpy: this is bookkeeping around the path, not the path.
+Evaluator.get_metrics runs them on the GPU (gpsr_bgr2gray + gpsr_metrics: integer window sums,
+fixed-order reductions); the numpy functions peak_signal_noise_ratio / structural_similarity below
+are the host-side equivalents for callers that hold numpy arrays and no device.
 """
 import os
 from collections import defaultdict
@@ -130,8 +132,7 @@ class Evaluator:
     def get_metrics(self, hr_image, upsampled_image, name):
         if upsampled_image is None:
             return PerceptualSimilarity(0, 0, 0)
-        a, b = self.preprocess_image(hr_image), self.preprocess_image(upsampled_image)
-        psnr, ssim = self.get_psnr(a, b), self.get_ssim(a, b)
+        psnr, ssim = self._metrics_gpu(hr_image, upsampled_image)
         if self.verbose:
             print(f'{name} - PSNR: {psnr:.3f}, SSIM: {ssim:.3f}')
         return PerceptualSimilarity(psnr, ssim)
@@ -145,6 +146,19 @@ class Evaluator:
         if preprocess:
             hr_image, upsampled_image = self.preprocess_image(hr_image), self.preprocess_image(upsampled_image)
         return structural_similarity(hr_image, upsampled_image, data_range=255)
+
+    def _metrics_gpu(self, hr_image, upsampled_image):
+        """PSNR and SSIM of two images as read from disk (BGR or grey uint8): grey conversion, crop by srf and both
+        reductions on the device (evaluation.py:83-98)."""
+        import torch
+        from . import ops
+        dev = torch.device("cuda", torch.cuda.current_device())
+
+        def grey(img):
+            t = torch.as_tensor(np.ascontiguousarray(img, dtype=np.uint8)).to(dev)
+            return ops.bgr2gray(t) if t.dim() == 3 else t
+        m = ops.metrics(grey(hr_image), grey(upsampled_image), self.srf).cpu().numpy()
+        return float(m[0]), float(m[1])
 
     def preprocess_image(self, image):
         if len(image.shape) == 3:

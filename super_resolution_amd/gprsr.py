@@ -98,18 +98,21 @@ class GPRSR:
         if self.warm_start == "chain_per_image" and self._chained():
             self._scoped_carry = torch.zeros((1, 4), dtype=torch.float32, device=_device())
         try:
+            # the colour image goes to the GPU once; conversion, chroma resize and merge are HIP kernels
+            bgr = torch.as_tensor(np.ascontiguousarray(lr_image, dtype=np.uint8)).to(_device())
+            sf = self.scaling_factor
             if self.color_mode == ColorSpace.GRAYSCALE:
-                g = self.apply_for_channel(imgproc.bgr2gray(lr_image))
-                img_out = np.stack([g, g, g], axis=-1)
+                g = self._channel_u8(ops.bgr2gray(bgr))
+                img_out = torch.stack([g, g, g], dim=-1)                      # cv.COLOR_GRAY2BGR
             elif self.color_mode == ColorSpace.YUV:
-                y, u, v = imgproc.bgr2yuv(lr_image)
-                y = self.apply_for_channel(y)
-                u = imgproc.resize_cubic_u8(u, fx=self.scaling_factor, fy=self.scaling_factor)
-                v = imgproc.resize_cubic_u8(v, fx=self.scaling_factor, fy=self.scaling_factor)
-                img_out = imgproc.yuv2bgr(y, u, v)
+                y, u, v = ops.bgr2yuv(bgr)
+                y = self._channel_u8(y)
+                u = imgproc.resize_cubic_u8_dev(u, fx=sf, fy=sf)
+                v = imgproc.resize_cubic_u8_dev(v, fx=sf, fy=sf)
+                img_out = ops.yuv2bgr(y, u, v)
             else:
-                chans = [self.apply_for_channel(np.ascontiguousarray(lr_image[..., i])) for i in range(3)]
-                img_out = np.stack(chans, axis=-1)
+                img_out = torch.stack([self._channel_u8(bgr[..., i].contiguous()) for i in range(3)], dim=-1)
+            img_out = img_out.cpu().numpy()
         finally:
             self._scoped_carry = None
         if DO_TIMING:
@@ -119,6 +122,10 @@ class GPRSR:
     # ------------------------------------------------------------------ one channel (gprsr.py:79-100)
     def apply_for_channel(self, lr_image_channel):
         return self.apply_for_channel_batch([lr_image_channel])[0]
+
+    def _channel_u8(self, ch):
+        """uint8 device plane -> uint8 device HR plane (gprsr.py:91-100 without leaving the GPU)."""
+        return ops.unit_to_u8(self.apply_for_channel_device([ops.u8_to_unit(ch)])[0], 255.0)
 
     def apply_for_channel_batch(self, channels):
         """Several uint8 channels/images at once: their patches share the GP batches."""

@@ -4,8 +4,10 @@ cv2 is not a dependency.  float64 images stay on the GPU: the host only builds
 the small per-axis index / coefficient tables the way OpenCV's resize.cpp does
 (float32 coefficient arithmetic, replicated border) and the HIP kernels
 (gpsr_resample, gpsr_decimate2, gpsr_sepfilter_sym, gpsr_filter3x3) apply them.
-uint8 colour conversion and the chroma resize are integer fixed-point host code
-(they are outside the GP path: gprsr.py:53-63, agpr.py:150-154).
+uint8 colour conversion and the chroma resize are integer fixed-point kernels as well
+(gpsr_bgr2gray / gpsr_bgr2yuv / gpsr_yuv2bgr / gpsr_bgr2ycrcb / gpsr_ycrcb2bgr / gpsr_resample_u8:
+gprsr.py:53-63, agpr.py:150-156), so GPRSR.apply moves a colour image to the GPU once; the numpy
+versions below remain for host-side callers (file loops, tests) and give the same bits.
 
 Reference call sites: gprsr.py:60-61,106 (INTER_CUBIC), gprsr.py:115 (default
 INTER_LINEAR, fx=1/s), gprsr.py:114 (GaussianBlur 5x5 sigma 0), agpr.py:245-246
@@ -110,7 +112,24 @@ def filter2d_3x3(img, kern):
     return ops.filter3x3(img, k)
 
 
-# ---------------------------------------------------------------- uint8 host code
+# ---------------------------------------------------------------- uint8 stages on the device
+def resize_cubic_u8_dev(img, fx=None, fy=None, dsize=None):
+    """cv.resize INTER_CUBIC on a uint8 device plane (the chroma planes, gprsr.py:60-61 / agpr.py:152-153)."""
+    H, W = img.shape
+    if dsize is None:
+        Wd, Hd, isx, isy = cv_round(W * fx), cv_round(H * fy), fx, fy
+    else:
+        Wd, Hd = dsize
+        isx, isy = Wd / W, Hd / H
+    xi, xw = _axis_tables(Wd, W, float(isx), "cubic")
+    yi, yw = _axis_tables(Hd, H, float(isy), "cubic")
+    dev = img.device
+    xa = torch.as_tensor(np.rint(xw * 2048).astype(np.int32)).to(dev)
+    ya = torch.as_tensor(np.rint(yw * 2048).astype(np.int32)).to(dev)
+    return ops.resample_u8(img, Hd, Wd, torch.as_tensor(xi).to(dev), xa, torch.as_tensor(yi).to(dev), ya)
+
+
+# ---------------------------------------------------------------- uint8 host code (host callers: file loops, tests)
 def _descale(x, n):
     return (x + (1 << (n - 1))) >> n
 

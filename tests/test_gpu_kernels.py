@@ -366,3 +366,87 @@ def test_covariance_grad_matches_oracle_and_finite_difference(kid):
     blk = np.add.outer(np.arange(K.shape[1]) // 112, -(np.arange(K.shape[1]) // 112)) >= 0
     scale = max(1e-30, np.abs(fd[:, blk]).max())
     assert np.abs(fd - dK)[:, blk].max() <= 2e-3 * scale
+
+
+# ----------------------------------------------------------------- uint8 colour stages + metrics (HIP, integer: bit-exact)
+def test_colour_kernels_bit_exact_vs_oracle():
+    """gpsr_bgr2gray / bgr2yuv / yuv2bgr / bgr2ycrcb / ycrcb2bgr / resample_u8 against oracle/cvops.py (OpenCV's
+    fixed-point paths restated; the grey table is pinned by the reference's own *_gray.png outputs)."""
+    from oracle import cvops
+    from super_resolution_amd import imgproc, ops
+    rng = np.random.default_rng(2)
+    bgr = rng.integers(0, 256, (97, 131, 3)).astype(np.uint8)
+    bgr[0, 0], bgr[0, 1], bgr[0, 2], bgr[0, 3], bgr[0, 4] = (0, 0, 0), (255, 255, 255), (255, 0, 0), (0, 255, 0), (0, 0, 255)
+    d = to_dev(bgr)
+    assert np.array_equal(ops.bgr2gray(d).cpu().numpy(), cvops.bgr2gray(bgr))
+    assert np.array_equal(imgproc.bgr2gray(bgr), cvops.bgr2gray(bgr))
+    y, u, v = ops.bgr2yuv(d)
+    want = cvops.bgr2yuv(bgr)
+    assert np.array_equal(torch.stack([y, u, v], -1).cpu().numpy(), want)
+    assert np.array_equal(ops.yuv2bgr(y, u, v).cpu().numpy(), cvops.yuv2bgr(want))
+    yy, cr, cb = ops.bgr2ycrcb(d)
+    want = cvops.bgr2ycrcb(bgr)
+    assert np.array_equal(torch.stack([yy, cr, cb], -1).cpu().numpy(), want)
+    assert np.array_equal(ops.ycrcb2bgr(yy, cr, cb).cpu().numpy(), cvops.ycrcb2bgr(want))
+    for kw in ({"fx": 3, "fy": 3}, {"fx": 2, "fy": 2}, {"dsize": (77, 50)}):
+        got = imgproc.resize_cubic_u8_dev(u, **kw).cpu().numpy()
+        assert np.array_equal(got, cvops.resize_cubic(u.cpu().numpy(), **kw)), kw
+
+
+@pytest.mark.parametrize("H,W,crop", [(64, 80, 3), (33, 29, 2), (240, 250, 4), (9, 9, 1)])
+def test_metrics_kernel_vs_oracle(H, W, crop):
+    """gpsr_metrics (PSNR, SSIM as evaluation.py:83-98 / skimage) against the oracle's numpy restatement: 1e-10."""
+    from oracle import cvops
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(H * W)
+    a = np.rint(natural_image(H, W, H) * 255).astype(np.uint8)
+    b = np.clip(a.astype(int) + rng.integers(-6, 7, a.shape), 0, 255).astype(np.uint8)
+    got = ops.metrics(to_dev(a), to_dev(b), crop).cpu().numpy()
+    ac, bc = a[crop:-crop, crop:-crop], b[crop:-crop, crop:-crop]
+    assert abs(got[0] - cvops.psnr(ac, bc)) < 1e-10
+    if min(ac.shape) >= 7:
+        assert abs(got[1] - cvops.ssim(ac, bc)) < 1e-10
+    assert abs(got[2] - np.mean((ac.astype(float) - bc) ** 2)) < 1e-12
+    same = ops.metrics(to_dev(a), to_dev(a), crop).cpu().numpy()
+    assert np.isinf(same[0]) and same[0] > 0 and (min(ac.shape) < 7 or abs(same[1] - 1.0) < 1e-12)
+    # deterministic: a second launch gives the same bits
+    assert np.array_equal(got, ops.metrics(to_dev(a), to_dev(b), crop).cpu().numpy())
+
+
+@pytest.mark.parametrize("kid,n", [(3, 324), (0, 784)])
+def test_near_singular_patch_needs_no_jitter(kid, n):
+    """Failure semantics (SURVEY.md 5.9 "Solver"): GPyTorch's psd_safe_cholesky adds jitter 1e-8 / 1e-7 / 1e-6 only
+    when the plain Cholesky FAILS.  The worst case the path can produce -- a patch whose feature rows repeat (a flat
+    image region: K without noise is singular), the noise at its 1e-4 floor and a huge outputscale, cond(K) ~ 1e12 --
+    factorises in float64 without any jitter, on the CPU (torch.linalg.cholesky does not throw) and here (no flag),
+    and the two agree to what that conditioning allows.  So the jitter ladder is never entered on finite input; a
+    non-finite patch is flagged and raised (test_non_finite_patch_raises_like_the_reference), GPyTorch's NanError."""
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(n + kid)
+    base = rng.random((n // 6, 8))
+    X = np.concatenate([base] * 6 + [rng.random((n - 6 * (n // 6), 8))])[:n]      # every row 6 times over
+    X[: n // 3] = X[0]                                                           # and a third of them identical
+    y = rng.random(n)
+    raw = np.array([[-30.0, 0.3, 2e5, 0.5]], dtype=np.float32)   # noise -> its 1e-4 floor, outputscale 2e5
+    Xd, yd, rd = to_dev(X[None]), to_dev(y[None]), to_dev(raw)
+    loss, grad, flags = ops.loss_grad(Xd, yd, kid, rd)
+    assert int(flags.sum()) == 0 and torch.isfinite(loss).all() and torch.isfinite(grad).all()
+    h = ogp.Hypers(*raw[0])
+    noise, c, os_, ls = [v.detach().double() for v in h.constrained()]
+    Xt, yt = torch.tensor(X), torch.tensor(y)
+    K = os_ * ogp.base_kernel(Xt, Xt, ls, kid) + noise * torch.eye(n, dtype=torch.float64)
+    cond = float(torch.linalg.cond(K))
+    assert cond > 1e11, cond
+    L = torch.linalg.cholesky(K)                     # the reference's first (jitter-free) attempt succeeds
+    want = float(ogp.neg_mll(h, Xt, yt, kid))
+    assert abs(float(loss[0]) - want) < 1e-3 * abs(want), (float(loss[0]), want)   # y^T K^-1 y carries cond x eps ~ 1e-4
+    # alpha and the predictive mean at these hyper-parameters (iters = 0: factorisation only)
+    alpha, fl = ops.fit(Xd, yd, kid, rd.clone(), iters=0)
+    assert int(fl.sum()) == 0
+    a_want = torch.cholesky_solve((yt - c)[:, None], L)[:, 0].numpy()
+    a_got = alpha[0, :n].cpu().numpy()
+    Xs = rng.random((50, 8))
+    m_want = (os_ * ogp.base_kernel(torch.tensor(Xs), Xt, ls, kid)).numpy() @ a_want + float(c)
+    m_got = ops.predict(Xd, to_dev(Xs[None]), alpha, rd, kid)[0].cpu().numpy()
+    # two CPU routes (Cholesky solve vs explicit inverse) differ by 8e-6 / 4e-5 here: 1e-3 is a quarter grey level
+    assert np.abs(m_got - m_want).max() < 1e-3, np.abs(m_got - m_want).max()

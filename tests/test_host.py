@@ -295,3 +295,51 @@ def test_sharded_predict_pixels_equals_unsharded_world2_gloo(tmp_path):
                        capture_output=True, text=True, env=env, timeout=240)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "rank0ok" in r.stdout and "rank1ok" in r.stdout
+
+
+# ----------------------------------------------------------------- bench.py starts its own ranks
+_RANK_STUB = r'''
+import os, sys, json, torch, torch.distributed as dist
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+dist.init_process_group("gloo", rank=rank, world_size=world)
+t = torch.tensor([float(rank + 1)])
+dist.all_reduce(t)
+if "--fail" in sys.argv and rank == 1:
+    sys.exit(3)
+if rank == 0:
+    print(json.dumps({"n_gpus": dist.get_world_size(), "sum": float(t.item())}), flush=True)
+dist.barrier()
+'''
+
+
+def test_bench_launcher_starts_ranks_relays_rank0_and_propagates_failures(tmp_path):
+    import json
+    import bench
+    stub = tmp_path / "stub.py"
+    stub.write_text(_RANK_STUB)
+    rc, out = bench.launch_ranks(2, [], script=str(stub), timeout=120)
+    assert rc == 0 and json.loads(out.strip().splitlines()[-1]) == {"n_gpus": 2, "sum": 3.0}
+    rc, out = bench.launch_ranks(3, [], script=str(stub), timeout=120)
+    assert rc == 0 and json.loads(out.strip().splitlines()[-1]) == {"n_gpus": 3, "sum": 6.0}
+    rc, _ = bench.launch_ranks(2, ["--fail"], script=str(stub), timeout=120)
+    assert rc != 0
+
+
+def test_bench_refuses_more_ranks_than_gpus():
+    """`python bench.py --gpus 2` on a box with fewer GPUs must fail loudly, not print n_gpus: 1."""
+    if torch.cuda.device_count() >= 2:
+        pytest.skip("box has >= 2 GPUs")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "GPSR_LOCAL_DEVICE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"],
+                       capture_output=True, text=True, env=env, timeout=300)
+    assert r.returncode != 0 and "GPU(s) visible" in r.stderr and '"n_gpus"' not in r.stdout
+
+
+def test_deal_chains_balances_whole_chains():
+    from super_resolution_amd.dist import deal_chains
+    lens = [49, 80, 49, 20, 20, 16, 35, 20, 49, 49, 77, 49, 72, 48]      # patches per Set14 x3 image (633)
+    for world in (1, 2, 4, 8):
+        owner = deal_chains(lens, world)
+        load = [sum(l for l, o in zip(lens, owner) if o == r) for r in range(world)]
+        assert sum(load) == sum(lens) and max(load) <= max(max(lens), -(-sum(lens) // world) + max(lens) // 2)

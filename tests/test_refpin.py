@@ -1,0 +1,79 @@
+"""The oracle against OUTPUT IMAGES THE REFERENCE ITSELF COMMITTED (tests/golden/refpin, written by
+tests/golden/make_refpin_fixtures.py from /root/reference/Set14/...: data files, no source).
+
+  Set14/image_SRF_2/img_001_SRF_2_GPR_matern52_gray.png   its name is gprsr.py:221-222 under the committed defaults
+      gprsr.py:17-22 (SRF 2, matern52, GRAYSCALE) and img_001 is the first image of that loop: a fresh process, the
+      kernel singleton at its initial values, then the warm-start chain over 240 patches x 2 phases.
+The live test below runs the whole reference pipeline restated in oracle/ -- cv.cvtColor(BGR2GRAY), /255, bicubic x2,
+480 chained GP fits (Matern-5/2, 50 Adam steps each), GaussianBlur 5x5, INTER_LINEAR 1/2, recombination, clip,
+truncating uint8 cast -- and demands the reference's PNG: measured 100.00 % identical pixels (max |diff| 0).
+With chain=False (independent starts) the same image is only 49 % identical (max 99 levels, 41.6 dB), with the
+14-bit grey table 99.17 %: the pin discriminates both.
+
+Measured once with tools/refpin_eval.py and not repeated here for time (each is minutes of CPU): img_002 continuing
+the chain from img_001 (810 s): 100.00 % identical; Set14/image_SRF_3/img_001_SRF_3_GPR_RBF.png (459 s): 100.00 %.
+GPSR_REFPIN_FULL=1 runs those too.  The HIP path is held to the same images in tests/test_gpu_refpin.py.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import cvops, gp as ogp, srgpr as osr
+
+
+def _load(golden_dir, name):
+    from PIL import Image
+    return np.array(Image.open(os.path.join(golden_dir, "refpin", name)))
+
+
+def _bgr(rgb):
+    return np.ascontiguousarray(rgb[:, :, ::-1])
+
+
+def _stats(got, ref):
+    d = np.abs(got.astype(int) - ref.astype(int))
+    return float((d == 0).mean()), int(d.max())
+
+
+def test_fixtures_are_what_the_script_describes(golden_dir):
+    lr, ref, hr = _load(golden_dir, "x2_lr_001.png"), _load(golden_dir, "x2_ref_m52_gray_001.png"), _load(golden_dir, "x2_hr_001.png")
+    assert lr.shape == (240, 250, 3) and ref.shape == hr.shape == (480, 500) and ref.dtype == np.uint8
+    # the reference's output is a plausible x2 of its input: PSNR vs HR as in SURVEY.md section 4 (judge: 23.678 dB)
+    c = 2
+    assert abs(cvops.psnr(hr[c:-c, c:-c], ref[c:-c, c:-c]) - 23.678) < 0.01
+    assert _load(golden_dir, "x3_ref_RBF_001.png").shape == (480, 498)
+
+
+def test_grey_table_is_opencvs_15_bit_one(golden_dir):
+    """bgr2gray: 15-bit RGB2Gray table; the 14-bit yuv_shift table differs on 69 of the 60 000 pixels of img_001."""
+    bgr = _bgr(_load(golden_dir, "x2_lr_001.png")).astype(np.int64)
+    g14 = (bgr[..., 0] * 1868 + bgr[..., 1] * 9617 + bgr[..., 2] * 4899 + (1 << 13)) >> 14
+    g = cvops.bgr2gray(_bgr(_load(golden_dir, "x2_lr_001.png")))
+    assert int((g != g14).sum()) == 69
+    assert np.array_equal(cvops.bgr2yuv(_bgr(_load(golden_dir, "x2_lr_001.png")))[..., 0], g14.astype(np.uint8))   # Y keeps the 14-bit one
+
+
+def test_oracle_chain_reproduces_the_references_x2_matern52_gray_output(golden_dir):
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    o = osr.OracleGPRSR(2, ogp.MATERN52, "GRAYSCALE", chain=True)
+    out = o.apply(_bgr(_load(golden_dir, "x2_lr_001.png")))
+    assert np.array_equal(out[..., 0], out[..., 1]) and np.array_equal(out[..., 0], out[..., 2])
+    ident, maxd = _stats(out[..., 0], _load(golden_dir, "x2_ref_m52_gray_001.png"))
+    print(f"oracle chain=True vs the reference's PNG: {100 * ident:.3f} % identical, max |diff| {maxd}")
+    assert ident >= 0.999 and maxd <= 1          # measured: 100 %, 0 (bit for bit)
+    assert o.shared.raw_os != 0.0                # the chain left its state behind, as the singleton does
+    if os.environ.get("GPSR_REFPIN_FULL"):
+        out2 = o.apply(_bgr(_load(golden_dir, "x2_lr_002.png")))           # second image of the same process
+        ident, maxd = _stats(out2[..., 0], _load(golden_dir, "x2_ref_m52_gray_002.png"))
+        assert ident >= 0.999 and maxd <= 1
+
+
+@pytest.mark.skipif(not os.environ.get("GPSR_REFPIN_FULL"), reason="minutes of CPU each; measured values in the module docstring")
+@pytest.mark.parametrize("kid,tag", [(ogp.RBF, "RBF"), (ogp.MATERN12, "matern12")])
+def test_oracle_reproduces_the_references_x3_outputs(golden_dir, kid, tag):
+    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    out = osr.OracleGPRSR(3, kid, "GRAYSCALE", chain=True).apply(_bgr(_load(golden_dir, "x3_lr_001.png")))
+    ident, maxd = _stats(out[..., 0], _load(golden_dir, f"x3_ref_{tag}_001.png"))
+    assert ident >= 0.999 and maxd <= 1
