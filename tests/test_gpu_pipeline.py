@@ -194,21 +194,35 @@ def test_set14_x3_final_hypers_close_to_oracle(golden_dir):
             assert np.median(err) < 1e-3 and (err < 1e-2).mean() > 0.95 and err.max() < 0.5, (i, phase, err.max())
 
 
-def test_loose_pin_against_the_references_own_output(golden_dir):
-    """img_001_SRF_3_GPR_matern52.png is an output image the reference's authors committed
-    (unknown settings, probably a chained multi-image run): the closest thing to a golden
-    vector of the whole pipeline incl. the OpenCV stages.  Loose bars only."""
-    from PIL import Image
+def test_set14_x3_chain_per_image_vs_oracle_chain_goldens(golden_dir):
+    """warm_start="chain_per_image" on ALL 14 Set14 x3 images at once (14 chains of 16..80 patches x 2 phases, link k
+    of every chain in one batched launch sequence) against the oracle's chain=True output per image
+    (tests/golden/set14_x3/oracle_m52_chain_*.png, tests/golden/make_set14_chain_goldens.py): north-star bar."""
     from super_resolution_amd.gprsr import GPRSR, ColorSpace
     from super_resolution_amd import kernels as K
+    from PIL import Image
     d = os.path.join(golden_dir, "set14_x3")
-    lr, hr = np.array(Image.open(f"{d}/lr_001.png")), np.array(Image.open(f"{d}/hr_001.png"))
-    ref = np.array(Image.open(f"{d}/refout_m52_001.png"))
-    got = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE).apply_for_channel(lr)
-    assert got.shape == ref.shape
-    assert cvops.psnr(ref, got) > 45.0                       # measured 46.8 dB between the two outputs
-    c = 3
-    assert abs(cvops.psnr(hr[c:-c, c:-c], got[c:-c, c:-c]) - cvops.psnr(hr[c:-c, c:-c], ref[c:-c, c:-c])) < 0.03
+    load = lambda n: np.array(Image.open(f"{d}/{n}"))
+    ids = list(range(1, 15))
+    g = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start="chain_per_image")
+    outs = g.apply_for_channel_batch([load(f"lr_{i:03d}.png") for i in ids])
+    ident = []
+    for i, got in zip(ids, outs):
+        want, hr = load(f"oracle_m52_chain_{i:03d}.png"), load(f"hr_{i:03d}.png")
+        dd = np.abs(got.astype(int) - want.astype(int))
+        assert dd.max() <= 1, f"img {i}: max |diff| {dd.max()}"
+        ident.append((dd == 0).mean())
+        c = 3
+        assert abs(cvops.psnr(hr[c:-c, c:-c], got[c:-c, c:-c]) - cvops.psnr(hr[c:-c, c:-c], want[c:-c, c:-c])) <= 0.01
+        assert abs(cvops.ssim(hr[c:-c, c:-c], got[c:-c, c:-c]) - cvops.ssim(hr[c:-c, c:-c], want[c:-c, c:-c])) <= 0.001
+    assert min(ident) > 0.999, ident
+    assert all(int(f.sum()) == 0 for f in g.stats.flags)
+    # the reference's own committed img_001_SRF_3_GPR_matern52.png (settings unknown: not the first image of a fresh
+    # process, or another stride): the chained result is 99.4 % identical to it, max 1 level (independent starts: 71 %,
+    # max 42) -- a loose pin only; the tight ones are in tests/test_gpu_refpin.py
+    ref = load("refout_m52_001.png")
+    dd = np.abs(outs[0].astype(int) - ref.astype(int))
+    assert dd.max() <= 1 and (dd == 0).mean() > 0.99
 
 
 @pytest.mark.parametrize("kid,s,chunk", [(3, 2, 0), (0, 3, 3), (2, 2, 4)])
