@@ -404,6 +404,82 @@ __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, d
   *ld += log(prod);
 }
 
+// 1/sqrt(x), x > 0: v_rsq_f64 seed + one third-order correction (relative error ~ e^3 of the seed's e <= 2^-23)
+__device__ __forceinline__ double rsqrt_pos(double x) {
+  const double y = __builtin_amdgcn_rsq(x);
+  const double e = fma(-x * y, y, 1.0);
+  return fma(y * e, fma(0.375, e, 0.5), y);
+}
+
+// broadcast of one accumulator element to the whole wave through scalar registers (lane index is a compile-time constant)
+__device__ __forceinline__ double bcast_lane(double v, int l) {
+  return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
+}
+
+// Same contract as chol16_inv for the inverse (m <- inv(chol(D)), *ld += log det D, *bad on a non-positive pivot; `a`
+// is consumed), four columns per step instead of one: the k-depth of v_mfma_f64_16x16x4_f64 is 4, so the rank-4
+// elimination of a 16x16 block is ONE instruction and the cross-lane shuffles of the column-by-column version (seven
+// ds_bpermute per column, 112 columns on the serial chain of a pivot block) disappear.  Step J (columns 4J..4J+3),
+// D = current Schur complement (symmetric, accumulator layout a[c](lr,lk) = D[lk+4c][lr]), M accumulates L^-1:
+//     L4 = chol(D_JJ), M4 = L4^-1        4x4 on ten values broadcast through scalar registers, every lane the same
+//     P  = D[:, 4J..4J+3] M4^T           (16 x 4)  one MFMA: A operand = M4 (lanes lr < 4), B operand = a[J], which
+//                                        by symmetry of D is D[:, 4J..4J+3] in B-operand layout; P comes out in
+//                                        A/B-operand layout (lane (lr,lk) = P[lr][lk])
+//     R  = M4 M[4J..4J+3, :]             (4 x 16)  one MFMA: A = M4, B = m[J]; these are the final rows of M
+//     D -= P P^T ;  M[rows > 4J+3, :] -= P R                                     one MFMA each
+__device__ __forceinline__ void chol16_inv_r4(double a[4], double m[4], int lane, double* ld, int* bad) {
+  const int lr = lane & 15, lk = lane >> 4;
+  v4d D = (v4d){a[0], a[1], a[2], a[3]};
+  v4d M;
+#pragma unroll
+  for (int c = 0; c < 4; ++c) M[c] = (lk + 4 * c == lr) ? 1.0 : 0.0;
+  double prod = 1.0;
+  const v4d zero4 = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int J = 0; J < 4; ++J) {
+    // D[4J+r][4J+c] sits in D[J] at lane (lr = 4J+c, lk = r)
+    const double dj = D[J];
+#define DJ(r, c) bcast_lane(dj, 4 * J + (c) + 16 * (r))
+    const double d00 = DJ(0, 0);
+    const double r0 = rsqrt_pos(d00);
+    const double l10 = DJ(1, 0) * r0, l20 = DJ(2, 0) * r0, l30 = DJ(3, 0) * r0;
+    const double p1 = fma(-l10, l10, DJ(1, 1));
+    const double r1 = rsqrt_pos(p1);
+    const double l21 = fma(-l20, l10, DJ(2, 1)) * r1, l31 = fma(-l30, l10, DJ(3, 1)) * r1;
+    const double p2 = fma(-l21, l21, fma(-l20, l20, DJ(2, 2)));
+    const double r2 = rsqrt_pos(p2);
+    const double l32 = fma(-l31, l21, fma(-l30, l20, DJ(3, 2))) * r2;
+    const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, DJ(3, 3))));
+    const double r3 = rsqrt_pos(p3);
+#undef DJ
+    if (!(d00 > 0.0) || !(p1 > 0.0) || !(p2 > 0.0) || !(p3 > 0.0)) *bad = 1;
+    prod *= (d00 * p1) * (p2 * p3);     // 16 pivots in [1e-4, 1e3]: no over/underflow; one log per block
+    const double m10 = -(l10 * r0) * r1;
+    const double m21 = -(l21 * r1) * r2;
+    const double m32 = -(l32 * r2) * r3;
+    const double m20 = -fma(l21, m10, l20 * r0) * r2;
+    const double m31 = -fma(l32, m21, l31 * r1) * r3;
+    const double m30 = -fma(l32, m20, fma(l31, m10, l30 * r0)) * r3;
+    // A operand of the P / R products: lane (lr, lk) holds M4[lr][lk] for lr < 4, zero elsewhere
+    double m4a = 0.0;
+    if (lr == 0) m4a = (lk == 0) ? r0 : 0.0;
+    else if (lr == 1) m4a = (lk == 0) ? m10 : (lk == 1 ? r1 : 0.0);
+    else if (lr == 2) m4a = (lk == 0) ? m20 : (lk == 1 ? m21 : (lk == 2 ? r2 : 0.0));
+    else if (lr == 3) m4a = (lk == 0) ? m30 : (lk == 1 ? m31 : (lk == 2 ? m32 : r3));
+    const v4d po = __builtin_amdgcn_mfma_f64_16x16x4f64(m4a, D[J], zero4, 0, 0, 0);
+    const v4d ro = __builtin_amdgcn_mfma_f64_16x16x4f64(m4a, M[J], zero4, 0, 0, 0);
+    const double P = (lr < 4 * J) ? 0.0 : po[0];          // rows of blocks already eliminated contribute nothing
+    const double Pm = (lr < 4 * J + 4) ? 0.0 : po[0];     // only rows below the block are eliminated in M
+    const double R = ro[0];
+    if (J < 3) D = __builtin_amdgcn_mfma_f64_16x16x4f64(-P, P, D, 0, 0, 0);
+    M = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pm, R, M, 0, 0, 0);
+    M[J] = R;                                             // rows 4J..4J+3 of M are final
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c) m[c] = M[c];
+  *ld += log(prod);
+}
+
 // Block-packed LDS image of the pivot block: the 28 lower 16x16 blocks, each [16][17];
 // (i,j), i >= j, at block index i(i+1)/2 + j.  60.9 KB + 15.2 KB of per-wave transpose
 // scratch = 76 KB -> two workgroups per CU (the 16x16 register factorisations are a serial,
@@ -453,7 +529,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
     double a[4], m[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) a[c] = SB(0, 0)[(lk + 4 * c) * PV_DLD + lr];
-    chol16_inv(a, m, lane, &ld, &bad);
+    chol16_inv_r4(a, m, lane, &ld, &bad);
 #pragma unroll
     for (int c = 0; c < 4; ++c) SB(0, 0)[(lk + 4 * c) * PV_DLD + lr] = m[c];
   }
@@ -491,7 +567,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
           double a[4], m[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) a[c] = acc[c];
-          chol16_inv(a, m, lane, &ld, &bad);
+          chol16_inv_r4(a, m, lane, &ld, &bad);
 #pragma unroll
           for (int c = 0; c < 4; ++c) Swj[(lk + 4 * c) * PV_DLD + lr] = m[c];
         } else {

@@ -56,7 +56,7 @@ def test_grey_table_is_opencvs_15_bit_one(golden_dir):
 
 
 def test_oracle_chain_reproduces_the_references_x2_matern52_gray_output(golden_dir):
-    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    torch.set_num_threads(min(4, os.cpu_count() or 1))   # 4 is faster than 8 here: the n = 324 factorisations are small
     o = osr.OracleGPRSR(2, ogp.MATERN52, "GRAYSCALE", chain=True)
     out = o.apply(_bgr(_load(golden_dir, "x2_lr_001.png")))
     assert np.array_equal(out[..., 0], out[..., 1]) and np.array_equal(out[..., 0], out[..., 2])
@@ -73,7 +73,7 @@ def test_oracle_chain_reproduces_the_references_x2_matern52_gray_output(golden_d
 @pytest.mark.skipif(not os.environ.get("GPSR_REFPIN_FULL"), reason="minutes of CPU each; measured values in the module docstring")
 @pytest.mark.parametrize("kid,tag", [(ogp.RBF, "RBF"), (ogp.MATERN12, "matern12")])
 def test_oracle_reproduces_the_references_x3_outputs(golden_dir, kid, tag):
-    torch.set_num_threads(min(8, os.cpu_count() or 1))
+    torch.set_num_threads(min(4, os.cpu_count() or 1))   # 4 is faster than 8 here: the n = 324 factorisations are small
     out = osr.OracleGPRSR(3, kid, "GRAYSCALE", chain=True).apply(_bgr(_load(golden_dir, "x3_lr_001.png")))
     ident, maxd = _stats(out[..., 0], _load(golden_dir, f"x3_ref_{tag}_001.png"))
     assert ident >= 0.999 and maxd <= 1

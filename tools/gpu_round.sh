@@ -1,15 +1,27 @@
 #!/bin/bash
-# One GPU-box session: tests, both bench modes, a kernel trace of the chained mode.  Every GPU step has its own limit
-# and the chain stops at the first failure.
+# One GPU-box session: tests, both bench modes, kernel traces (rocprofv3 --stats) of both, PMC passes.  Every GPU step
+# has its own limit and the chain stops at the first failure.
 set -o pipefail
+R=${ROUND:-r02}
 mkdir -p gpurun_out
-timeout -k 10 1000 python -u -m pytest tests -m gpu -x -q --timeout 600 --timeout-method thread -s > gpurun_out/t2.log 2>&1
+if [ "${SKIP_TESTS:-0}" != "1" ]; then
+timeout -k 10 1100 python -u -m pytest tests -m gpu -x -q --timeout 600 --timeout-method thread -s > gpurun_out/t2.log 2>&1
 rc=$?; echo "pytest rc=$rc" | tee -a gpurun_out/t2.log; tail -3 gpurun_out/t2.log
 [ $rc -eq 0 ] || exit $rc
-timeout -k 10 400 python -u bench.py --steps 3 --warmup 1 > gpurun_out/bench_indep.json 2> gpurun_out/bench_indep.err || { echo bench_indep failed; tail -5 gpurun_out/bench_indep.err; exit 1; }
-cat gpurun_out/bench_indep.json | cut -c1-600
-timeout -k 10 400 python -u bench.py --warm-start chain_per_image --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/bench_chain.json 2> gpurun_out/bench_chain.err || { echo bench_chain failed; tail -5 gpurun_out/bench_chain.err; exit 1; }
-cat gpurun_out/bench_chain.json | cut -c1-600
+fi
+timeout -k 10 400 python -u bench.py --steps 3 --warmup 1 > gpurun_out/${R}_bench_set14x3.json 2> gpurun_out/bench_indep.err || { echo bench_indep failed; tail -5 gpurun_out/bench_indep.err; exit 1; }
+cut -c1-400 gpurun_out/${R}_bench_set14x3.json
+timeout -k 10 400 python -u bench.py --warm-start chain_per_image --steps 2 --warmup 1 --no-cpu-baseline > gpurun_out/${R}_bench_set14x3_chain_per_image.json 2> gpurun_out/bench_chain.err || { echo bench_chain failed; tail -5 gpurun_out/bench_chain.err; exit 1; }
+cut -c1-400 gpurun_out/${R}_bench_set14x3_chain_per_image.json
+timeout -k 10 400 python -u bench.py --workload 4kx2 --steps 1 --warmup 1 --no-cpu-baseline > gpurun_out/${R}_bench_4kx2.json 2> gpurun_out/bench_4k.err || { echo bench_4k failed; tail -5 gpurun_out/bench_4k.err; exit 1; }
+cut -c1-400 gpurun_out/${R}_bench_4kx2.json
+ROOT=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/prof_chain -o chain -- python3 $GRAFT_REPO_ROOT/bench.py --warm-start chain_per_image --steps 1 --warmup 0 --no-cpu-baseline > $GRAFT_REPO_ROOT/gpurun_out/prof_chain.log 2>&1 || { echo rocprof failed; tail -5 $GRAFT_REPO_ROOT/gpurun_out/prof_chain.log; exit 1; }
-ls $GRAFT_REPO_ROOT/gpurun_out/prof_chain | head
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_indep -o indep -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $ROOT/gpurun_out/${R}_bench_set14x3_under_rocprof.json 2> $ROOT/gpurun_out/prof_indep.log || { echo rocprof indep failed; tail -5 $ROOT/gpurun_out/prof_indep.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_chain -o chain -- python3 $ROOT/bench.py --warm-start chain_per_image --steps 1 --warmup 0 --no-cpu-baseline > $ROOT/gpurun_out/prof_chain.json 2> $ROOT/gpurun_out/prof_chain.log || { echo rocprof chain failed; tail -5 $ROOT/gpurun_out/prof_chain.log; exit 1; }
+cd $ROOT
+if [ "${SKIP_PMC:-0}" != "1" ]; then
+bash tools/pmc_run.sh gpurun_out/pmc324 10800 324 eval && python3 tools/pmc_summarize.py gpurun_out/pmc324 gpurun_out/${R}_pmc_eval_10800x324.json 10800 324 eval || exit 1
+bash tools/pmc_run.sh gpurun_out/pmc784 633 784 invert && python3 tools/pmc_summarize.py gpurun_out/pmc784 gpurun_out/${R}_pmc_invert_633x784.json 633 784 invert || exit 1
+fi
+echo round-ok

@@ -22,7 +22,7 @@ def short(name):
     return m.group(1) if m else None
 
 
-def main(src, dst):
+def main(src, dst, B=633, N=784, mode="invert"):
     acc = defaultdict(lambda: defaultdict(lambda: [0, 0.0]))
     csv.field_size_limit(1 << 30)
     for path in sorted(glob.glob(os.path.join(src, "**", "*counter_collection.csv"), recursive=True)):
@@ -34,8 +34,10 @@ def main(src, dst):
                 a = acc[k][row["Counter_Name"]]
                 a[0] += 1
                 a[1] += float(row["Counter_Value"])
+    what = (f"one batched inversion of {B} SPD matrices of order {N}" if mode == "invert" else
+            f"one whole fit evaluation (covariance, sweeps, alpha, gradient statistics) of {B} GPs with n = {N}, Matern-3/2")
     out = {"command": "tools/pmc_run.sh: rocprofv3 --pmc <group> --kernel-trace, one counter group per run, on "
-                      "tools/pmc_invert.py 633 784 1 (one batched inversion of 633 SPD matrices of order 784 = 7 pivot steps)",
+                      f"tools/pmc_invert.py {B} {N} 1 {mode} ({what})",
            "units": "FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 reports them; other counters raw",
            "kernels": {k: {c: {"launches": v[0], "mean_per_launch": v[1] / v[0]} for c, v in sorted(cs.items())}
                        for k, cs in sorted(acc.items())}}
@@ -45,6 +47,10 @@ def main(src, dst):
             f, w = cs["FETCH_SIZE"]["mean_per_launch"] * 1024, cs["WRITE_SIZE"]["mean_per_launch"] * 1024
             out["hbm_bytes_per_launch"][kname] = {"fetch_raw": f, "fetch_corrected_x2": 2 * f, "write": w,
                                                   "traffic_corrected": 2 * f + w}
+    tot = sum(v["traffic_corrected"] * out["kernels"][k]["FETCH_SIZE"]["launches"] for k, v in out["hbm_bytes_per_launch"].items())
+    raw = sum((v["fetch_raw"] + v["write"]) * out["kernels"][k]["FETCH_SIZE"]["launches"] for k, v in out["hbm_bytes_per_launch"].items())
+    out["hbm_bytes_per_gp"] = {"corrected_upper_bound": tot / B, "uncorrected": raw / B,
+                               "note": "all launches of the run (k_* kernels) / number of GPs"}
     out["hbm_note"] = ("x2 is the guide's gfx950 correction for 16 B/lane reads (the LDS-DMA operand chunks); the C-tile "
                        "reads are 8 B/lane and uncalibrated, so the corrected figure is an upper bound")
     with open(dst, "w") as f:
@@ -53,4 +59,4 @@ def main(src, dst):
 
 
 if __name__ == "__main__":
-    main(sys.argv[1], sys.argv[2])
+    main(sys.argv[1], sys.argv[2], *([int(sys.argv[3]), int(sys.argv[4]), sys.argv[5]] if len(sys.argv) > 5 else []))
