@@ -985,3 +985,14 @@ extern "C" int gpsr_debug_upd_trace(unsigned long long* out8) {
   return e == hipSuccess ? 0 : hip_fail(e, "trace clear");
 }
 #endif
+
+#ifdef GPSR_PIV_TRACE
+// debug build only (tools/piv_trace.py): read (and clear) the k_pivot phase cycle counters
+extern "C" int gpsr_debug_piv_trace(unsigned long long* out8) {
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_piv_trace), 8 * sizeof(unsigned long long));
+  if (e != hipSuccess) return hip_fail(e, "trace read");
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  e = hipMemcpyToSymbol(HIP_SYMBOL(g_piv_trace), z, sizeof(z));
+  return e == hipSuccess ? 0 : hip_fail(e, "trace clear");
+}
+#endif

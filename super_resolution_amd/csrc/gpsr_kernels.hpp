@@ -361,49 +361,6 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
 // sqrt(cond) digits per level (measured: DESIGN.md "Numerics of the inversion").
 #define PV_DLD 17
 
-// In registers, C/D lane layout (lane: lr = lane&15, lk = lane>>4; a[c] = D[lk+4c][lr]):
-// a <- L16 = chol(D) (zeros above the diagonal), m <- inv(L16); *ld += log det D.
-__device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, double* ld, int* bad) {
-  const int lr = lane & 15, lk = lane >> 4;
-#pragma unroll
-  for (int c = 0; c < 4; ++c) m[c] = (lk + 4 * c == lr) ? 1.0 : 0.0;
-  double prod = 1.0;
-#pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int jr = j & 3, jc = j >> 2;
-    // D[j][j]: lane index is a compile-time constant -> scalar broadcast (v_readlane), off the LDS crossbar
-    const double pv = __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(a[jc]), j + 16 * jr),
-                                       __builtin_amdgcn_readlane(__double2loint(a[jc]), j + 16 * jr));
-    const double cl = __shfl(a[jc], lr + 16 * jr);   // D[j][lr]   (row j; used for lr > j)
-    const double mj = __shfl(m[jc], lr + 16 * jr);   // M[j][lr]
-    double ci[4];
-#pragma unroll
-    for (int c = 0; c < 4; ++c) ci[c] = __shfl(a[c], j + 16 * lk);  // D[lk+4c][j] (column j)
-    if (!(pv > 0.0)) *bad = 1;
-    prod *= pv;                     // 16 pivots in [1e-4, 1e3]: no over/underflow; one log per tile
-    const double rinv = rsqrt(pv);
-    const double clr = cl * rinv;   // L[lr][j]
-    const double mjs = mj * rinv;   // row j of M, final
-#pragma unroll
-    for (int c = 0; c < 4; ++c) {
-      const int i = lk + 4 * c;
-      const double lij = ci[c] * rinv;  // L[i][j] (i >= j)
-      double av = a[c];
-      if (lr == j) av = (i >= j) ? lij : 0.0;
-      else if (lr > j && i > j) av = fma(-lij, clr, av);
-      a[c] = av;
-      double mv = m[c];
-      if (i > j) mv = fma(-lij, mjs, mv);
-      if (c == jc && lk == jr) mv = mjs;
-      m[c] = mv;
-    }
-  }
-#pragma unroll
-  for (int c = 0; c < 4; ++c)
-    if (lr > lk + 4 * c) a[c] = 0.0;
-  *ld += log(prod);
-}
-
 // 1/sqrt(x), x > 0: v_rsq_f64 seed + one third-order correction (relative error ~ e^3 of the seed's e <= 2^-23)
 __device__ __forceinline__ double rsqrt_pos(double x) {
   const double y = __builtin_amdgcn_rsq(x);
@@ -416,10 +373,11 @@ __device__ __forceinline__ double bcast_lane(double v, int l) {
   return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), l), __builtin_amdgcn_readlane(__double2loint(v), l));
 }
 
-// Same contract as chol16_inv for the inverse (m <- inv(chol(D)), *ld += log det D, *bad on a non-positive pivot; `a`
-// is consumed), four columns per step instead of one: the k-depth of v_mfma_f64_16x16x4_f64 is 4, so the rank-4
-// elimination of a 16x16 block is ONE instruction and the cross-lane shuffles of the column-by-column version (seven
-// ds_bpermute per column, 112 columns on the serial chain of a pivot block) disappear.  Step J (columns 4J..4J+3),
+// 16x16 SPD block in registers, accumulator lane layout (lr = lane&15, lk = lane>>4; a[c] = D[lk+4c][lr]):
+// m <- inv(chol(D)) in the same layout, *ld += log det D, *bad on a non-positive pivot.  Four columns per step:
+// the k-depth of v_mfma_f64_16x16x4_f64 is 4, so the rank-4 elimination of the block is ONE instruction and no
+// cross-lane shuffle is needed (the column-by-column version of round 1 spent seven ds_bpermute per column; this one
+// is 2-4 % faster per pivot launch: the serial chain is the 4x4 scalar factorisation either way).  Step J (columns 4J..4J+3),
 // D = current Schur complement (symmetric, accumulator layout a[c](lr,lk) = D[lk+4c][lr]), M accumulates L^-1:
 //     L4 = chol(D_JJ), M4 = L4^-1        4x4 on ten values broadcast through scalar registers, every lane the same
 //     P  = D[:, 4J..4J+3] M4^T           (16 x 4)  one MFMA: A operand = M4 (lanes lr < 4), B operand = a[J], which
@@ -427,7 +385,7 @@ __device__ __forceinline__ double bcast_lane(double v, int l) {
 //                                        A/B-operand layout (lane (lr,lk) = P[lr][lk])
 //     R  = M4 M[4J..4J+3, :]             (4 x 16)  one MFMA: A = M4, B = m[J]; these are the final rows of M
 //     D -= P P^T ;  M[rows > 4J+3, :] -= P R                                     one MFMA each
-__device__ __forceinline__ void chol16_inv_r4(double a[4], double m[4], int lane, double* ld, int* bad) {
+__device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, double* ld, int* bad) {
   const int lr = lane & 15, lk = lane >> 4;
   v4d D = (v4d){a[0], a[1], a[2], a[3]};
   v4d M;
@@ -488,10 +446,24 @@ __device__ __forceinline__ void chol16_inv_r4(double a[4], double m[4], int lane
 #define PV_NBLK (NBT * (NBT + 1) / 2)
 #define SB(i, j) (S + (((i) * ((i) + 1)) / 2 + (j)) * PV_BLK)
 
+#ifdef GPSR_PIV_TRACE
+// Debug build only (tools/piv_trace.py): cycles of a k_pivot workgroup by phase, summed over workgroups (stamped by
+// thread 0 right after the barrier that ends each phase): [0] workgroups, [1] load, [2] blocked Cholesky,
+// [3] M = L^-1, [4] P = M^T M + stores of A_kk, [5] U / M stores, [6] entry -> exit.
+__device__ unsigned long long g_piv_trace[8];
+#define PIV_STAMP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_piv_trace[i], t_ - piv_t); piv_t = t_; } } while (0)
+#else
+#define PIV_STAMP(i)
+#endif
+
 __global__ void __launch_bounds__(MM_THREADS, 4)
 k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double* __restrict__ Mbuf,
         double* __restrict__ logdet, int32_t* __restrict__ flags) {
   extern __shared__ double sm[];
+#ifdef GPSR_PIV_TRACE
+  unsigned long long piv_t = __builtin_readcyclecounter();
+  const unsigned long long piv_t0 = piv_t;
+#endif
   double* S = sm;                           // [PV_NBLK][16][PV_DLD]
   double* Tr = sm + PV_NBLK * PV_BLK;       // [NBT waves][16][PV_DLD] per-wave transpose scratch
   const int b = blockIdx.x, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
@@ -516,6 +488,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
     for (int i = 0; i < PV_NBLK * 128 / MM_THREADS; ++i) { S[dst[i]] = v[i].x; S[dst[i] + 1] = v[i].y; }
   }
   __syncthreads();
+  PIV_STAMP(1);
   double ld = 0.0;
   int bad = 0;
   double* tr = Tr + wave * PV_BLK;
@@ -529,7 +502,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
     double a[4], m[4];
 #pragma unroll
     for (int c = 0; c < 4; ++c) a[c] = SB(0, 0)[(lk + 4 * c) * PV_DLD + lr];
-    chol16_inv_r4(a, m, lane, &ld, &bad);
+    chol16_inv(a, m, lane, &ld, &bad);
 #pragma unroll
     for (int c = 0; c < 4; ++c) SB(0, 0)[(lk + 4 * c) * PV_DLD + lr] = m[c];
   }
@@ -567,7 +540,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
           double a[4], m[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) a[c] = acc[c];
-          chol16_inv_r4(a, m, lane, &ld, &bad);
+          chol16_inv(a, m, lane, &ld, &bad);
 #pragma unroll
           for (int c = 0; c < 4; ++c) Swj[(lk + 4 * c) * PV_DLD + lr] = m[c];
         } else {
@@ -578,6 +551,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
     }
     __syncthreads();
   }
+  PIV_STAMP(2);
   // every wave factored one diagonal block: combine log-determinant and flags
   {
     __shared__ double ldsum[NBT];
@@ -622,6 +596,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
     }
     __syncthreads();
   }
+  PIV_STAMP(3);
   // ---------------- phase 3: P = M^T M, wave a computes P[a, 0..a]; A_kk <- -P (both triangles)
   {
     const int a = wave;
@@ -643,6 +618,8 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
       }
     }
   }
+  __syncthreads();
+  PIV_STAMP(4);
   // ---------------- phase 4: the non-zero 16x16 blocks of M (lower) and U = M^T (upper) to global.
   // The zero blocks are never written: the panel / update kernels skip the products that would read them.
   double* Ub = Ubuf + (size_t)b * NB * NB;
@@ -662,6 +639,11 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
     logdet[b] += ld;
     if (bad) flags[b] = 1;
   }
+#ifdef GPSR_PIV_TRACE
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  PIV_STAMP(5);
+  if (tid == 0) { atomicAdd(&g_piv_trace[0], 1ull); atomicAdd(&g_piv_trace[6], __builtin_readcyclecounter() - piv_t0); }
+#endif
 }
 #define PIVOT_LDS_BYTES ((PV_NBLK * PV_BLK + NBT * PV_BLK) * sizeof(double))
 
