@@ -46,6 +46,13 @@ enum {
 enum { GPSR_COMBINE_AVERAGE = 0, GPSR_COMBINE_BILINEAR = 1 };
 
 #define GPSR_BLOCK 112 /* pivot-block / tile edge of the batched inversion */
+/*
+ * Matrix layout of K / A / dK_dl below: TILE-BLOCKED.  A matrix of padded order N = nblk * GPSR_BLOCK is stored as
+ * [nblk][nblk][GPSR_BLOCK][GPSR_BLOCK] doubles: tile (I, J) is one contiguous row-major 112 x 112 block at offset
+ * (I * nblk + J) * 112 * 112, element (i, j) of the matrix sits in tile (i / 112, j / 112) at [i % 112][j % 112].
+ * (N * N doubles per matrix, as for row-major; for N = 112 the two layouts coincide.)  Only tiles with I >= J are
+ * written / maintained ("lower block-triangle"), diagonal tiles full.
+ */
 
 /* Library version string ("gpsr <x.y> gfx950"). */
 const char* gpsr_version(void);
@@ -111,7 +118,7 @@ int gpsr_init_hypers(const double* y, int B, int n, int kernel_id,
 
 /*
  * K2 covariance.  K[b] = outputscale * k(X_b, X_b) + noise * I  as the lower
- * block-triangle (GPSR_BLOCK tiles, diagonal tiles full) of a [N][N] matrix,
+ * block-triangle (GPSR_BLOCK tiles, diagonal tiles full) of a tile-blocked matrix of order
  * N = gpsr_padded_n(n); rows/cols >= n are identity.  Replaces GPyTorch's
  * kernel forward + likelihood noise reached from kernels.py:21-24 and
  * gprsr.py:183-184.   X : [B][n][d]   raw : [B][4]   K : [B][N][N]
@@ -130,7 +137,7 @@ int gpsr_covariance_grad(const double* X, int B, int n, int d, int kernel_id,
 
 /*
  * In-place batched SPD inversion by blocked symmetric Gauss-Jordan sweeps
- * (MFMA f64 trailing updates).  On return A[b] holds -inv(A[b]) in the lower
+ * (MFMA f64 trailing updates).  A: tile-blocked (see above).  On return A[b] holds -inv(A[b]) in the lower
  * block-triangle, logdet[b] = log det A[b].  Workspace: gpsr_invert_workspace_bytes.
  * This is the factorisation the fit uses instead of GPyTorch's dense Cholesky
  * (linear_operator psd_safe_cholesky reached from gprsr.py:184-185).

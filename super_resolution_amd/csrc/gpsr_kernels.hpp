@@ -1,9 +1,13 @@
 // gpsr_kernels.hpp -- device code of the batched GP super-resolution engine (gfx950 only).
 //
 // Layout conventions
-//   A      [B][N][N] f64 row-major, N = nblk*NB.  Only block (I,J) with I>=J is
-//          maintained ("lower block-triangle"); diagonal blocks are kept full.
-//   Wo     [B][NB][N]  k-major panel of the current pivot step, W = A_.k L^-T: Wo[kk][r] = W[r][kk]
+//   A      [B][nblk][nblk][NB][NB] f64, N = nblk*NB: TILE-BLOCKED -- tile (I,J) of a matrix is one contiguous
+//          row-major [NB][NB] block (100 KB), so the 16-row strip a wave reads / writes and every LDS-DMA chunk
+//          is one contiguous range instead of 16 row segments N*8 bytes apart (round 1 measured -6.5 % on the
+//          update kernels for contiguous C accesses).  Only tiles (I,J) with I>=J are maintained ("lower
+//          block-triangle"); diagonal tiles are kept full.
+//   Wo     [B][nblk][NB][NB]  k-major panel of the current pivot step, W = A_.k L^-T, one contiguous
+//          [kk][r] block per row block I: Wo[I][kk][r] = W[I*NB + r][kk]
 //   U, M   [B][NB][NB] U = L^-T (upper), M = L^-1 (lower) of the current pivot block A_kk = L L^T
 //   raw    [B][4] f32  raw hyper-parameters (noise, const, outputscale, lengthscale)
 //
@@ -21,6 +25,7 @@
 #define NBT 7           // NB / 16 : MFMA tiles per edge == waves per workgroup
 #define MM_THREADS 448  // 64 * NBT
 #define KC 16           // k-chunk staged through LDS
+#define TILE_OFF(I, J, nblk) ((size_t)((I) * (nblk) + (J)) * (size_t)(NB * NB))   // tile (I,J) inside one matrix
 
 typedef double v4d __attribute__((ext_vector_type(4)));
 
@@ -254,7 +259,7 @@ __global__ void k_build(const double* __restrict__ X, const float* __restrict__ 
     } else {
       val = (gi == gj) ? 1.0 : 0.0;
     }
-    Ab[(size_t)gi * N + gj] = val;
+    Ab[TILE_OFF(I, J, N / NB) + (size_t)i * NB + j] = val;
   }
 }
 
@@ -289,7 +294,7 @@ __global__ void k_build_dl(const double* __restrict__ X, const float* __restrict
       kv = h.os * kv + (gi == gj ? h.noise : 0.0);
       dk = h.os * dk;
     }
-    const size_t off = (size_t)b * N * N + (size_t)gi * N + gj;
+    const size_t off = (size_t)b * N * N + TILE_OFF(I, J, N / NB) + (size_t)i * NB + j;
     if (A) A[off] = kv;
     dA[off] = dk;
   }
@@ -330,7 +335,7 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
   const Hyp h = load_hyp(raw + 4 * b);
   if (t == 0 && tid == 0 && logdet) logdet[b] = 0.0;
   __syncthreads();
-  double* Ab = A + (size_t)b * N * N + (size_t)(I * NB) * N + gj;
+  double* Ab = A + (size_t)b * N * N + TILE_OFF(I, J, N / NB) + j;
 #pragma unroll 2
   for (int i = i0; i < iend; i += istep) {
     const int gi = I * NB + i;
@@ -342,7 +347,7 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
     } else {
       val = (gi == gj) ? 1.0 : 0.0;
     }
-    Ab[(size_t)i * N] = val;
+    Ab[(size_t)i * NB] = val;
   }
 }
 
@@ -468,7 +473,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   double* Tr = sm + PV_NBLK * PV_BLK;       // [NBT waves][16][PV_DLD] per-wave transpose scratch
   const int b = blockIdx.x, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
-  double* Akk = A + (size_t)b * N * N + (size_t)(k * NB) * N + k * NB;
+  double* Akk = A + (size_t)b * N * N + TILE_OFF(k, k, N / NB);   // the pivot tile: contiguous [NB][NB]
   // 28 blocks x 16 rows x 8 units of 16 B = 3584 units = 8 per thread: all 8 loads are issued
   // before the first LDS store, so the block arrives in one memory latency instead of sixteen
   {
@@ -481,7 +486,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
       int bi = 0;
       while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
       const int bj = blk - bi * (bi + 1) / 2;
-      v[i] = *(const double2*)(Akk + (size_t)(16 * bi + r) * N + 16 * bj + c);
+      v[i] = *(const double2*)(Akk + (size_t)(16 * bi + r) * NB + 16 * bj + c);
       dst[i] = blk * PV_BLK + r * PV_DLD + c;
     }
 #pragma unroll
@@ -613,8 +618,8 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
       }
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        Akk[(size_t)(16 * a + lk + 4 * c) * N + 16 * bb + lr] = -acc[c];
-        if (bb != a) Akk[(size_t)(16 * bb + lr) * N + 16 * a + lk + 4 * c] = -acc[c];
+        Akk[(size_t)(16 * a + lk + 4 * c) * NB + 16 * bb + lr] = -acc[c];
+        if (bb != a) Akk[(size_t)(16 * bb + lr) * NB + 16 * a + lk + 4 * c] = -acc[c];
       }
     }
   }
@@ -949,31 +954,31 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
   }
   if (trailing) {
     if (G1) grad1_stage_r(rv, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, J, tid);
-    const double* Aop = Wo + (size_t)b * NB * N + I * NB;   // used negated
-    const double* Bop = Wo + (size_t)b * NB * N + J * NB;
-    double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + J * NB + lr;
+    const double* Aop = Wo + (size_t)b * NB * N + (size_t)I * (NB * NB);   // used negated
+    const double* Bop = Wo + (size_t)b * NB * N + (size_t)J * (NB * NB);
+    double* Ct = Ab + TILE_OFF(I, J, nblk) + (size_t)(16 * wave + lk) * NB + lr;
     if (I == J) {
       // symmetric diagonal tile: wave w computes the 16x16 blocks t <= w and mirrors t < w
 #pragma unroll
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * N + 16 * t] : 0.0;
-      tile_product_dma<SKIP_DIAG, true>(Aop, N, Bop, N, lds, acc, wave, lane);
+        for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * NB + 16 * t] : 0.0;
+      tile_product_dma<SKIP_DIAG, true>(Aop, NB, Bop, NB, lds, acc, wave, lane);
 #pragma unroll
       for (int t = 0; t < NBT; ++t) {
         if (t > wave) break;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
       }
       __syncthreads();   // chunk buffers are free: per-wave transposition scratch
-      store_strip_transposed(acc, Ab + (size_t)(I * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr, wave);
+      store_strip_transposed(acc, Ab + TILE_OFF(I, I, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
       if (G1) grad1_partials(acc, true, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
     } else {
-      tile_product_dma_latec(Aop, N, Bop, N, lds, acc, Ct, (size_t)N, wave, lane);
+      tile_product_dma_latec(Aop, NB, Bop, NB, lds, acc, Ct, (size_t)NB, wave, lane);
 #pragma unroll
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
       if (G1) {
         __syncthreads();   // every wave is out of the chunk loop: the LDS buffers are free
         grad1_partials(acc, false, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
@@ -981,20 +986,20 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
     }
   } else {
     if (G1) grad1_stage_r(rv, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, k, tid);
-    const double* Aop = Wo + (size_t)b * NB * N + I * NB;
+    const double* Aop = Wo + (size_t)b * NB * N + (size_t)I * (NB * NB);
     const double* Bop = Mbuf + (size_t)b * NB * NB;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_product_dma<SKIP_LOWER, false>(Aop, N, Bop, NB, lds, acc, wave, lane);
+    tile_product_dma<SKIP_LOWER, false>(Aop, NB, Bop, NB, lds, acc, wave, lane);
     if (I > k) {
-      double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + k * NB + lr;
+      double* Ct = Ab + TILE_OFF(I, k, nblk) + (size_t)(16 * wave + lk) * NB + lr;
 #pragma unroll
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
     } else {
       __syncthreads();
-      store_strip_transposed(acc, Ab + (size_t)(k * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr);
+      store_strip_transposed(acc, Ab + TILE_OFF(k, I, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr);
     }
     if (G1) {
       __syncthreads();
@@ -1029,40 +1034,41 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
   double* Ab = A + (size_t)b * N * N;
   const double* W1 = Wo1 + (size_t)b * NB * N;
   const double* W2 = Wo2 + (size_t)b * NB * N;
+#define WT(I) ((size_t)(I) * (NB * NB))   // row block I of a tile-blocked panel
   v4d acc[NBT];
   if (t0 < ntri2) {                                   // (a)
     int I, J; tri_decode(t0, I, J);
     if (I >= k1) I += 2;
     if (J >= k1) J += 2;
-    double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + J * NB + lr;
+    double* Ct = Ab + TILE_OFF(I, J, nblk) + (size_t)(16 * wave + lk) * NB + lr;
     if (I == J) {
 #pragma unroll
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * N + 16 * t] : 0.0;
-      tile_product_dma2<SKIP_DIAG, true, SKIP_DIAG, true, false>(W1 + I * NB, N, W1 + J * NB, N, W2 + I * NB, N,
-                                                                 W2 + J * NB, N, lds, acc, Ct, (size_t)N, wave, lane);
+        for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * NB + 16 * t] : 0.0;
+      tile_product_dma2<SKIP_DIAG, true, SKIP_DIAG, true, false>(W1 + WT(I), NB, W1 + WT(J), NB, W2 + WT(I), NB,
+                                                                 W2 + WT(J), NB, lds, acc, Ct, (size_t)NB, wave, lane);
 #pragma unroll
       for (int t = 0; t < NBT; ++t) {
         if (t > wave) break;
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
       }
       __syncthreads();
-      store_strip_transposed(acc, Ab + (size_t)(I * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr, wave);
+      store_strip_transposed(acc, Ab + TILE_OFF(I, I, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
     } else {
 #ifdef GPSR_UPD_TRACE
       const unsigned long long trc_t1 = TRC_CLK();
 #endif
-      tile_product_dma2<SKIP_NONE, true, SKIP_NONE, true, true>(W1 + I * NB, N, W1 + J * NB, N, W2 + I * NB, N,
-                                                                W2 + J * NB, N, lds, acc, Ct, (size_t)N, wave, lane);
+      tile_product_dma2<SKIP_NONE, true, SKIP_NONE, true, true>(W1 + WT(I), NB, W1 + WT(J), NB, W2 + WT(I), NB,
+                                                                W2 + WT(J), NB, lds, acc, Ct, (size_t)NB, wave, lane);
 #ifdef GPSR_UPD_TRACE
       const unsigned long long trc_t2 = TRC_CLK();
 #endif
 #pragma unroll
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
 #ifdef GPSR_UPD_TRACE
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // stores retired: what the workgroup slot really costs
       const unsigned long long trc_t3 = TRC_CLK();
@@ -1078,51 +1084,53 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
     int I = t0 - ntri2; if (I >= k1) I += 2;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_product_dma2<SKIP_LOWER, false, SKIP_NONE, true, false>(W1 + I * NB, N, M1buf + (size_t)b * NB * NB, NB,
-                                                                 W2 + I * NB, N, W2 + k1 * NB, N, lds, acc, nullptr,
+    tile_product_dma2<SKIP_LOWER, false, SKIP_NONE, true, false>(W1 + WT(I), NB, M1buf + (size_t)b * NB * NB, NB,
+                                                                 W2 + WT(I), NB, W2 + WT(k1), NB, lds, acc, nullptr,
                                                                  0, wave, lane);
     if (I > k1) {
-      double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + k1 * NB + lr;
+      double* Ct = Ab + TILE_OFF(I, k1, nblk) + (size_t)(16 * wave + lk) * NB + lr;
 #pragma unroll
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
     } else {
       __syncthreads();
-      store_strip_transposed(acc, Ab + (size_t)(k1 * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr);
+      store_strip_transposed(acc, Ab + TILE_OFF(k1, I, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr);
     }
   } else if (t0 == ntri2 + nb2) {                     // (c)
-    double* Ct = Ab + (size_t)(k1 * NB + 16 * wave + lk) * N + k1 * NB + lr;
+    double* Ct = Ab + TILE_OFF(k1, k1, nblk) + (size_t)(16 * wave + lk) * NB + lr;
 #pragma unroll
     for (int t = 0; t < NBT; ++t)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * N + 16 * t] : 0.0;
-    tile_product_dma<SKIP_DIAG, true>(W2 + k1 * NB, N, W2 + k1 * NB, N, lds, acc, wave, lane);
+      for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * NB + 16 * t] : 0.0;
+    tile_product_dma<SKIP_DIAG, true>(W2 + WT(k1), NB, W2 + WT(k1), NB, lds, acc, wave, lane);
 #pragma unroll
     for (int t = 0; t < NBT; ++t) {
       if (t > wave) break;
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+      for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
     }
     __syncthreads();
-    store_strip_transposed(acc, Ab + (size_t)(k1 * NB) * N + k1 * NB, (size_t)N, lds, wave, lane, 1.0, nullptr, wave);
+    store_strip_transposed(acc, Ab + TILE_OFF(k1, k1, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
   } else {                                            // (d)
     int I = t0 - (ntri2 + nb2 + 1); if (I >= k2) ++I;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_product_dma<SKIP_LOWER, false>(W2 + I * NB, N, M2buf + (size_t)b * NB * NB, NB, lds, acc, wave, lane);
+    tile_product_dma<SKIP_LOWER, false>(W2 + WT(I), NB, M2buf + (size_t)b * NB * NB, NB, lds, acc, wave, lane);
     if (I > k2) {
-      double* Ct = Ab + (size_t)(I * NB + 16 * wave + lk) * N + k2 * NB + lr;
+      double* Ct = Ab + TILE_OFF(I, k2, nblk) + (size_t)(16 * wave + lk) * NB + lr;
 #pragma unroll
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
-        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * N + 16 * t] = acc[t][rr];
+        for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
     } else {
       __syncthreads();
-      store_strip_transposed(acc, Ab + (size_t)(k2 * NB) * N + I * NB, (size_t)N, lds, wave, lane, 1.0, nullptr);
+      store_strip_transposed(acc, Ab + TILE_OFF(k2, I, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr);
     }
   }
 }
+
+#undef WT
 
 // ------------------------------------------------------------------ panel
 // grid.x = (nblk-1) * B.  For row block i != k, T = A_ik:  W = T L^-T = T U, stored k-major,
@@ -1174,11 +1182,11 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
   const double* U = Ubuf + (size_t)b * NB * NB;
   const int i0 = i * NB, k0 = k * NB;
   const bool below = i > k;
-  const double* Tsrc = below ? Ab + (size_t)i0 * N + k0 : Ab + (size_t)k0 * N + i0;
+  const double* Tsrc = below ? Ab + TILE_OFF(i, k, nblk) : Ab + TILE_OFF(k, i, nblk);
   v4d acc[NBT];
 #pragma unroll
   for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-  dma_chunk_panel(Tsrc, (size_t)N, below, U, 0, lds, lds + DMA_CHUNK, wave, lane);
+  dma_chunk_panel(Tsrc, (size_t)NB, below, U, 0, lds, lds + DMA_CHUNK, wave, lane);
   const int r = 16 * wave + lr, rsw = (r >> 1) & 7;
 #pragma unroll
   for (int ch = 0; ch < NB / KC; ++ch) {
@@ -1187,7 +1195,7 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
     double* nxt = lds + ((ch + 1) & 1) * 2 * DMA_CHUNK;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    if (ch + 1 < NB / KC) dma_chunk_panel(Tsrc, (size_t)N, below, U, ch + 1, nxt, nxt + DMA_CHUNK, wave, lane);
+    if (ch + 1 < NB / KC) dma_chunk_panel(Tsrc, (size_t)NB, below, U, ch + 1, nxt, nxt + DMA_CHUNK, wave, lane);
 #pragma unroll
     for (int ks = 0; ks < KC / 4; ++ks) {
       const int kk = ks * 4 + lk;
@@ -1202,7 +1210,7 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
   }
   __syncthreads();
   // acc[t][rr] = W[r = 16*wave + lk + 4rr][k' = 16t + lr]  ->  Wo[k'][i0 + r]
-  store_strip_transposed(acc, Wo + (size_t)b * NB * N + i0, (size_t)N, lds, wave, lane, 1.0, nullptr);
+  store_strip_transposed(acc, Wo + (size_t)b * NB * N + (size_t)i * (NB * NB), (size_t)NB, lds, wave, lane, 1.0, nullptr);
 }
 
 // ------------------------------------------------------------------ grad1
@@ -1285,9 +1293,9 @@ k_grad1r(const double* __restrict__ A, int N, int n, int nblk, int k, const doub
     if (tid < NB) { const int gj = k * NB + tid; rk[tid] = gj < n ? yb[gj] - mean : 0.0; }
     __syncthreads();
     const int c = tid % NB, g = tid / NB;
-    const double* Akk = Ab + (size_t)(k * NB) * N + k * NB;
+    const double* Akk = Ab + TILE_OFF(k, k, nblk);
     double sacc = 0.0;
-    for (int j = g; j < NB; j += 4) sacc = fma(Akk[(size_t)j * N + c], rk[j], sacc);
+    for (int j = g; j < NB; j += 4) sacc = fma(Akk[(size_t)j * NB + c], rk[j], sacc);
     pk[g][c] = sacc;
     __syncthreads();
   }
@@ -1307,7 +1315,7 @@ k_grad1r(const double* __restrict__ A, int N, int n, int nblk, int k, const doub
     alpha[(size_t)b * N + gi] = al;
     if (gi < n) {
       const double ri = yb[gi] - mean;
-      st[0] = -Ab[(size_t)gi * N + gi];
+      st[0] = -Ab[TILE_OFF(R, R, nblk) + (size_t)tid * NB + tid];
       st[1] = al * al; st[2] = al * ri; st[3] = al;
     }
   }
@@ -1357,7 +1365,7 @@ __global__ void k_grad2(const double* __restrict__ A, const double* __restrict__
     int i = e / NB, j = e % NB;
     int gi = I * NB + i, gj = J * NB + j;
     if (gi < n && gj < n) {
-      double w = -Ab[(size_t)gi * N + gj] - ai[i] * aj[j];
+      double w = -Ab[TILE_OFF(I, J, N / NB) + (size_t)i * NB + j] - ai[i] * aj[j];
       double st = pair_stat<KID>(xi + i * ldx, xj + j * ldx, d);
       double kv, dk;
       kern_val_dl<KID>(st, h, kv, dk);
@@ -1413,13 +1421,13 @@ k_grad2_8(const double* __restrict__ A, const double* __restrict__ X, const floa
   if (tid < NB) ai[tid] = alpha[(size_t)b * N + I * NB + tid];
   const Hyp h = load_hyp(raw + 4 * b);
   __syncthreads();
-  const double* Ab = A + (size_t)b * N * N + (size_t)(I * NB) * N + gj;
+  const double* Ab = A + (size_t)b * N * N + TILE_OFF(I, J, N / NB) + j;
   double s0 = 0.0, s1 = 0.0;
   if (gj < n) {
 #pragma unroll 2
     for (int i = i0; i < iend; i += istep) {
       if (I * NB + i < n) {
-        const double w = wsym * (-Ab[(size_t)i * N] - ai[i] * aj);
+        const double w = wsym * (-Ab[(size_t)i * NB] - ai[i] * aj);
         const double st = pair_stat<KID>(xi + i * 8, xj, 8);
         double kv, dk;
         kern_val_dl<KID>(st, h, kv, dk);

@@ -38,6 +38,20 @@ def padded_n(n):
     return ((n + BLOCK - 1) // BLOCK) * BLOCK
 
 
+def block(A):
+    """[B,N,N] row-major -> the library's tile-blocked layout [B][N/112][N/112][112][112] (same shape, a copy)."""
+    B, N, _ = A.shape
+    nb = N // BLOCK
+    return A.view(B, nb, BLOCK, nb, BLOCK).permute(0, 1, 3, 2, 4).contiguous().view(B, N, N)
+
+
+def unblock(Ab):
+    """Inverse of block(): tile-blocked -> [B,N,N] row-major (a copy)."""
+    B, N, _ = Ab.shape
+    nb = N // BLOCK
+    return Ab.view(B, nb, nb, BLOCK, BLOCK).permute(0, 1, 3, 2, 4).contiguous().view(B, N, N)
+
+
 def gather(train_in, train_tgt, test_in, s, p, locs, tidx):
     """-> X [B,n,8], y [B,n], Xs [B,m,8]   (gpsr_gather)."""
     lib = _lib.load()
@@ -76,11 +90,11 @@ def covariance(X, kernel_id, raw):
     K = torch.zeros((B, N, N), dtype=torch.float64, device=X.device)
     _lib.check(lib.gpsr_covariance(_p(X, torch.float64), B, n, d, kernel_id, _p(raw, torch.float32), _p(K),
                                    _stream()), "gpsr_covariance")
-    return K
+    return unblock(K)      # row-major for Python callers; the library's layout is tile-blocked (include/gpsr.h)
 
 
 def covariance_grad(X, kernel_id, raw):
-    """-> K, dK/dlengthscale (x outputscale), both [B,N,N] lower block-triangle (gpsr_covariance_grad)."""
+    """-> K, dK/dlengthscale (x outputscale), both [B,N,N] row-major, lower block-triangle valid (gpsr_covariance_grad)."""
     lib = _lib.load()
     B, n, d = X.shape
     N = padded_n(n)
@@ -88,19 +102,22 @@ def covariance_grad(X, kernel_id, raw):
     dK = torch.zeros((B, N, N), dtype=torch.float64, device=X.device)
     _lib.check(lib.gpsr_covariance_grad(_p(X, torch.float64), B, n, d, kernel_id, _p(raw, torch.float32), _p(K),
                                         _p(dK), _stream()), "gpsr_covariance_grad")
-    return K, dK
+    return unblock(K), unblock(dK)
 
 
 def invert_(A):
-    """In-place: A[b] <- -inv(A[b]) (lower block-triangle).  Returns logdet, flags."""
+    """In-place on a row-major [B,N,N] tensor: A[b] <- -inv(A[b]) (lower block-triangle).  Returns logdet, flags.
+    (The library works on the tile-blocked layout: converted on the way in and out.)"""
     lib = _lib.load()
     B, N, _ = A.shape
     nbytes = lib.gpsr_invert_workspace_bytes(B, N)
     ws = torch.empty(nbytes, dtype=torch.uint8, device=A.device)
     logdet = torch.empty(B, dtype=torch.float64, device=A.device)
     flags = torch.empty(B, dtype=torch.int32, device=A.device)
-    _lib.check(lib.gpsr_invert(_p(A, torch.float64), B, N, _p(logdet), _p(flags), _p(ws), nbytes, _stream()),
+    Ab = block(A)
+    _lib.check(lib.gpsr_invert(_p(Ab, torch.float64), B, N, _p(logdet), _p(flags), _p(ws), nbytes, _stream()),
                "gpsr_invert")
+    A.copy_(unblock(Ab))
     return logdet, flags
 
 
