@@ -109,11 +109,10 @@ class BatchedGP:
         m = Xs.shape[1]
         nch = len(lens)
         assert sum(lens) == B and carry.shape == (nch, 4)
-        pred = torch.empty((B, m), dtype=torch.float64, device=dev)
         raw = torch.empty((B, 4), dtype=torch.float32, device=dev)
         flags = torch.empty(B, dtype=torch.int32, device=dev)
         if B == 0:
-            return pred, raw, flags
+            return torch.empty((B, m), dtype=torch.float64, device=dev), raw, flags
         # longest chain first: the chains still running at link k are then a prefix of `order`
         order = sorted(range(nch), key=lambda j: -lens[j])
         offs = np.concatenate([[0], np.cumsum(lens)])[:-1]
@@ -126,18 +125,22 @@ class BatchedGP:
         order_t = torch.as_tensor(np.asarray(order, dtype=np.int64)).to(dev)
         cur = carry.index_select(0, order_t).contiguous()      # [nch,4] in `order`
         ws = self._workspace(min(nch, B), n, d, dev)
+        alpha_all = torch.empty((B, ops.padded_n(n)), dtype=torch.float64, device=dev)
         pos = 0
         for k, bk in enumerate(steps):
             idx = idx_all[pos:pos + bk]
             pos += bk
-            Xk, yk, Xsk = X.index_select(0, idx), y.index_select(0, idx), Xs.index_select(0, idx)
+            Xk, yk = X.index_select(0, idx), y.index_select(0, idx)
             r = ops.init_hypers(yk, self.kernel_id, carry=cur[:bk])
             alpha, fl = ops.fit(Xk, yk, self.kernel_id, r, self.iters, self.lr, ws)
-            pred.index_copy_(0, idx, ops.predict(Xk, Xsk, alpha, r, self.kernel_id))
+            alpha_all.index_copy_(0, idx, alpha)
             raw.index_copy_(0, idx, r)
             flags.index_copy_(0, idx, fl)
             cur[:bk] = r
         carry.index_copy_(0, order_t, cur)
+        # the predictive means do not feed the chain: one batched launch for all links at the end (the mean of a GP
+        # depends on its own X, alpha and hyper-parameters only), instead of one small launch per link
+        pred = ops.predict(X, Xs, alpha_all, raw, self.kernel_id)
         return pred, raw, flags
 
 
