@@ -190,17 +190,24 @@ static InvWs inv_ws_carve(char* base, int B, int N) {
 static const bool g_pair_steps = getenv("GPSR_SINGLE_STEPS") == nullptr;   // debugging switch: one pivot per pass
 
 static int launch_pivot(double* A, int B, int N, int k, double* U, double* M, double* logdet, int32_t* flags,
-                        hipStream_t st) {
+                        int with_p, hipStream_t st) {
   ProfRec* pr = prof_start(T_PIVOT, st);
-  hipLaunchKernelGGL(k_pivot, dim3(B), dim3(MM_THREADS), PIVOT_LDS_BYTES, st, A, N, k, U, M, logdet, flags);
+  hipLaunchKernelGGL(k_pivot, dim3(B), dim3(MM_THREADS), PIVOT_LDS_BYTES, st, A, N, k, U, M, logdet, flags, with_p);
   prof_stop(pr, st);
   CHECK_LAUNCH("k_pivot");
   return 0;
 }
+// Small batches run the tile products in strip mode (gpsr_kernels.hpp): one wave per workgroup, seven workgroups per tile.
+// Used while the launch in strip form still fits the GPU at once (two such workgroups per CU): measured on n = 784, B = 1, 2
+// every launch is 10-35 % shorter, at B = 4 the panel and the restricted update still are, the full updates no longer.
+static const bool g_strip = getenv("GPSR_NO_STRIP") == nullptr;   // debugging switch
+static inline bool strip_mode(int tiles) { return g_strip && tiles * NBT <= 512; }
+
 static int launch_panel(const double* A, int B, int N, int k, const double* U, double* Wo, hipStream_t st) {
   const int nblk = N / NB, tp = (nblk - 1) * B;
   ProfRec* pr = prof_start(T_PANEL, st);
-  hipLaunchKernelGGL(k_panel, dim3(tp), dim3(MM_THREADS), 0, st, A, N, nblk, k, U, Wo, tp);
+  if (strip_mode(tp)) hipLaunchKernelGGL(k_panel<true>, dim3(tp * NBT), dim3(64), 0, st, A, N, nblk, k, U, Wo, tp * NBT);
+  else hipLaunchKernelGGL(k_panel<false>, dim3(tp), dim3(MM_THREADS), 0, st, A, N, nblk, k, U, Wo, tp);
   prof_stop(pr, st);
   CHECK_LAUNCH("k_panel");
   return 0;
@@ -251,7 +258,8 @@ extern "C" size_t gpsr_fit_workspace_bytes(int B, int n, int d) {
 // launches over the same batch.  They are written down as a list of operations first and issued
 // afterwards, so that the same list can drive one batch on one stream or two half-batches on two streams.
 enum { OP_BUILD, OP_PIVOT, OP_PANEL, OP_UPD_SEL, OP_UPD2, OP_UPD, OP_GRAD1, OP_GRAD2, OP_ADAM };
-struct Op { int kind, k, set, arg; bool heavy; };   // set: which (U, M, Wo) triple; arg: OP_UPD last flag / OP_ADAM iteration
+struct Op { int kind, k, set, arg; bool heavy; };   // set: which (U, M, Wo) triple; arg: OP_UPD last flag / OP_ADAM iteration /
+                                                    // OP_PIVOT: the pivot forms tile (k,k) = -M^T M itself (mark_pivots)
 
 struct Batch {   // one batch (or half-batch) of GPs and its buffers
   int B;
@@ -265,6 +273,27 @@ struct Batch {   // one batch (or half-batch) of GPs and its buffers
 };
 struct FitShape { int n, N, d, kid; float lr; bool with_part; };
 
+// Tile (k,k) = -M^T M of a pivot step is formed either by k_pivot itself (its phase 3) or, as one more tile product, by
+// the update launch that follows.  The second takes 12-19 % off the latency-bound pivot launch and is free while the
+// update launch fits the GPU in one round of workgroups; in a large batch the extra workgroup slot costs more than the
+// pivot saves (633 x n=784: update2 +5 %, 10 800 x n=324: +20 %).  The alpha-epilogue instantiation stays free of the
+// extra role, single-block matrices have no update.  OP_PIVOT.arg = kind of the update launch that follows (0: none).
+enum { PT_NONE = 0, PT_UPD = 1, PT_UPD2 = 2 };
+static void mark_pivots(Op* ops, int nops) {
+  for (int i = 0; i < nops; ++i) {
+    if (ops[i].kind != OP_PIVOT) continue;
+    int j = i + 1;
+    while (j < nops && ops[j].kind != OP_UPD && ops[j].kind != OP_UPD2) ++j;
+    ops[i].arg = (j == nops || (ops[j].kind == OP_UPD && ops[j].arg)) ? PT_NONE : (ops[j].kind == OP_UPD ? PT_UPD : PT_UPD2);
+  }
+}
+static const bool g_ptile = getenv("GPSR_NO_PTILE") == nullptr;   // debugging switch
+static inline bool update_forms_ptile(int pt_kind, int B, int nblk) {
+  if (!g_ptile || pt_kind == PT_NONE) return false;
+  const int nb2 = nblk - 2;
+  const int per = pt_kind == PT_UPD ? (nblk - 1) * nblk / 2 + nblk : nb2 * (nb2 + 1) / 2 + nb2 + 1 + nblk;
+  return per * B <= 512;
+}
 // pivots are taken two at a time while at least one single step remains for the end (the alpha epilogue
 // lives in the single-step kernel): nblk odd -> (nblk-1)/2 pairs + 1 single, even -> (nblk-2)/2 pairs + 2
 static void append_sweep_ops(std::vector<Op>& ops, int nblk, bool with_part) {
@@ -285,6 +314,7 @@ static void append_sweep_ops(std::vector<Op>& ops, int nblk, bool with_part) {
       ops.push_back({OP_UPD, k, 0, (k == nblk - 1 && with_part) ? 1 : 0, true});
     }
   }
+  mark_pivots(ops.data(), (int)ops.size());
 }
 static void append_eval_ops(std::vector<Op>& ops, int nblk, bool with_grad) {
   ops.push_back({OP_BUILD, 0, 0, 0, true});
@@ -326,36 +356,49 @@ static int launch_op(const Op& op, const Batch& h, const FitShape& c) {
     case OP_BUILD:
       return launch_build(h.X, B, c.n, N, c.d, c.kid, h.raw, w.A, w.logdet, st, 0);   // diagonal tiles: lower sub-blocks only
     case OP_PIVOT:
-      return launch_pivot(w.A, B, N, op.k, w.inv.U[op.set], w.inv.M[op.set], w.logdet, h.flags, st);
+      return launch_pivot(w.A, B, N, op.k, w.inv.U[op.set], w.inv.M[op.set], w.logdet, h.flags, update_forms_ptile(op.arg, B, nblk) ? 0 : 1, st);
     case OP_PANEL:
       return launch_panel(w.A, B, N, op.k, w.inv.U[op.set], Wo, st);
     case OP_UPD_SEL: {
       const int tu = nblk * B;   // the tiles of block row / column k+1 only
       pr = prof_start(T_UPDATE_SEL, st);
-      hipLaunchKernelGGL(k_update<false>, dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
-                         ntri1, tu, (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, op.k + 1);
+      if (strip_mode(tu))
+        hipLaunchKernelGGL((k_update<false, true>), dim3(tu * NBT), dim3(64), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
+                           ntri1, tu * NBT, (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, op.k + 1, 0);
+      else
+        hipLaunchKernelGGL((k_update<false, false>), dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
+                           ntri1, tu, (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, op.k + 1, 0);
       prof_stop(pr, st);
       CHECK_LAUNCH("k_update(sel)");
       return 0;
     }
     case OP_UPD2: {
-      const int nb2 = nblk - 2, per = nb2 * (nb2 + 1) / 2 + nb2 + 1 + nblk - 1, tu = per * B;
+      const int pt = update_forms_ptile(PT_UPD2, B, nblk) ? 1 : 0;
+      const int nb2 = nblk - 2, per = nb2 * (nb2 + 1) / 2 + nb2 + 1 + nblk - 1 + pt, tu = per * B;
       pr = prof_start(T_UPDATE2, st);
-      hipLaunchKernelGGL(k_update2, dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.Wo2,
-                         w.inv.M[0], w.inv.M[1], tu);
+      if (strip_mode(tu))
+        hipLaunchKernelGGL(k_update2<true>, dim3(tu * NBT), dim3(64), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.Wo2,
+                           w.inv.M[0], w.inv.M[1], tu * NBT, pt);
+      else
+        hipLaunchKernelGGL(k_update2<false>, dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.Wo2,
+                           w.inv.M[0], w.inv.M[1], tu, pt);
       prof_stop(pr, st);
       CHECK_LAUNCH("k_update2");
       return 0;
     }
     case OP_UPD: {
-      const int tu = (ntri1 + nblk - 1) * B;
+      const int pt = (!op.arg && update_forms_ptile(PT_UPD, B, nblk)) ? 1 : 0;   // + tile (k,k), see mark_pivots
+      const int tu = (ntri1 + nblk - 1 + pt) * B;
       pr = prof_start(op.arg ? T_UPDATE_LAST : T_UPDATE, st);
       if (op.arg)
-        hipLaunchKernelGGL(k_update<true>, dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
-                           ntri1, tu, h.y, (const float*)h.raw, c.n, w.part, -1);
+        hipLaunchKernelGGL((k_update<true, false>), dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
+                           ntri1, tu, h.y, (const float*)h.raw, c.n, w.part, -1, 0);
+      else if (strip_mode(tu))
+        hipLaunchKernelGGL((k_update<false, true>), dim3(tu * NBT), dim3(64), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
+                           ntri1, tu * NBT, (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, -1, pt);
       else
-        hipLaunchKernelGGL(k_update<false>, dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
-                           ntri1, tu, (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, -1);
+        hipLaunchKernelGGL((k_update<false, false>), dim3(tu), dim3(MM_THREADS), 0, st, w.A, N, nblk, op.k, w.inv.Wo, w.inv.M[0],
+                           ntri1, tu, (const double*)nullptr, (const float*)nullptr, 0, (double*)nullptr, -1, pt);
       prof_stop(pr, st);
       CHECK_LAUNCH("k_update");
       return 0;
@@ -627,6 +670,7 @@ extern "C" int gpsr_fit_noalloc(const double* X, const double* y, int B, int n, 
       }
     }
     ops[nops++] = {OP_GRAD1, 0, 0, 0, false};
+    mark_pivots(ops, nops);
   }
   if ((rc = ensure_lds_attrs())) return rc;
   const Op grad2 = {OP_GRAD2, 0, 0, 0, true};

@@ -358,8 +358,8 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
 //            hand as the B operand of the sub-panel product with no LDS hand-off)
 //   phase 2  M = L^-1 by block forward substitution (wave q owns column block q);
 //            M^T =: U is kept in the (otherwise unused) strictly-upper blocks of S
-//   phase 3  P = M^T M = U U^T  ->  A_kk <- -P   (the pivot block of -A^-1)
-//   phase 4  U and M go to global for the panel / update kernels.
+//   phase 3  P = M^T M = U U^T  ->  A_kk <- -P   (the pivot block of -A^-1; with_p, else left to the update launch)
+//   U and M go to global for the panel / update kernels block by block, as each becomes final.
 // Everything outside the 16x16 register kernels is f64 MFMA.  Cholesky form on both
 // levels (W = T L^-T, A -= W W^T, T <- W L^-1) keeps the error at the level of an
 // unblocked sweep; forming A -= (T P) T^T with an explicit block inverse loses
@@ -461,9 +461,22 @@ __device__ unsigned long long g_piv_trace[8];
 #define PIV_STAMP(i)
 #endif
 
+// 16x16 block (bi,bj) of M = L^-1 from the accumulator layout (v[c] = block[lk+4c][lr]) to global: M[bi][bj] and
+// U[bj][bi] = its transpose.  Issued as soon as a block is final, so the stores drain behind the remaining steps
+// instead of after them (the zero blocks are never written: the panel / update kernels skip the products that would
+// read them).
+__device__ __forceinline__ void store_mu_block(double* __restrict__ Mb, double* __restrict__ Ub, int bi, int bj,
+                                               const double v[4], int lr, int lk) {
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    Mb[(16 * bi + lk + 4 * c) * NB + 16 * bj + lr] = v[c];
+    Ub[(16 * bj + lr) * NB + 16 * bi + lk + 4 * c] = v[c];
+  }
+}
+
 __global__ void __launch_bounds__(MM_THREADS, 4)
 k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double* __restrict__ Mbuf,
-        double* __restrict__ logdet, int32_t* __restrict__ flags) {
+        double* __restrict__ logdet, int32_t* __restrict__ flags, int with_p) {
   extern __shared__ double sm[];
 #ifdef GPSR_PIV_TRACE
   unsigned long long piv_t = __builtin_readcyclecounter();
@@ -497,6 +510,8 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   double ld = 0.0;
   int bad = 0;
   double* tr = Tr + wave * PV_BLK;
+  double* Ub = Ubuf + (size_t)b * NB * NB;
+  double* Mb = Mbuf + (size_t)b * NB * NB;
   // ---------------- phase 1: blocked Cholesky; afterwards SB(q,q) = inv(L16_q), SB(w,q) = L[w,q]
   // The 16x16 factor+inverse is a serial register kernel: ONE wave (the owner of the diagonal
   // block) runs it and publishes inv(L16_q) in place.
@@ -510,6 +525,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
     chol16_inv(a, m, lane, &ld, &bad);
 #pragma unroll
     for (int c = 0; c < 4; ++c) SB(0, 0)[(lk + 4 * c) * PV_DLD + lr] = m[c];
+    store_mu_block(Mb, Ub, 0, 0, m, lr, lk);
   }
   __syncthreads();
   for (int q = 0; q < NBT - 1; ++q) {
@@ -548,6 +564,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
           chol16_inv(a, m, lane, &ld, &bad);
 #pragma unroll
           for (int c = 0; c < 4; ++c) Swj[(lk + 4 * c) * PV_DLD + lr] = m[c];
+          store_mu_block(Mb, Ub, wave, wave, m, lr, lk);
         } else {
 #pragma unroll
           for (int c = 0; c < 4; ++c) Swj[(lk + 4 * c) * PV_DLD + lr] = acc[c];
@@ -598,12 +615,17 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
       double* Swq = SB(wave, q);
 #pragma unroll
       for (int c = 0; c < 4; ++c) Swq[(lk + 4 * c) * PV_DLD + lr] = res[c];
+      const double rv[4] = {res[0], res[1], res[2], res[3]};
+      store_mu_block(Mb, Ub, wave, q, rv, lr, lk);
     }
     __syncthreads();
   }
   PIV_STAMP(3);
-  // ---------------- phase 3: P = M^T M, wave a computes P[a, 0..a]; A_kk <- -P (both triangles)
-  {
+  // ---------------- phase 3: P = M^T M, wave a computes P[a, 0..a]; A_kk <- -P (both triangles).
+  // Only when nothing follows that can do it (with_p: single-block matrices, the step before the alpha epilogue):
+  // otherwise the update launch of the same step forms -M^T M as one more tile product (form_ptile: same products in
+  // the same order, bit-identical), next to its other tiles instead of on this latency-bound workgroup's path.
+  if (with_p) {
     const int a = wave;
     for (int bb = 0; bb <= a; ++bb) {
       v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
@@ -625,21 +647,6 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   }
   __syncthreads();
   PIV_STAMP(4);
-  // ---------------- phase 4: the non-zero 16x16 blocks of M (lower) and U = M^T (upper) to global.
-  // The zero blocks are never written: the panel / update kernels skip the products that would read them.
-  double* Ub = Ubuf + (size_t)b * NB * NB;
-  double* Mb = Mbuf + (size_t)b * NB * NB;
-#pragma unroll
-  for (int i = 0; i < PV_NBLK * 128 / MM_THREADS; ++i) {   // 16-byte units, as in the load
-    const int u = tid + MM_THREADS * i;
-    const int blk = u >> 7, r = (u >> 3) & 15, c = (u & 7) * 2;
-    int bi = 0;
-    while ((bi + 1) * (bi + 2) / 2 <= blk) ++bi;
-    const int bj = blk - bi * (bi + 1) / 2;
-    const double* Sb = S + blk * PV_BLK;
-    *(double2*)(Mb + (16 * bi + r) * NB + 16 * bj + c) = make_double2(Sb[r * PV_DLD + c], Sb[r * PV_DLD + c + 1]);      // M[i][j]
-    *(double2*)(Ub + (16 * bj + r) * NB + 16 * bi + c) = make_double2(Sb[c * PV_DLD + r], Sb[(c + 1) * PV_DLD + r]);    // U[j][i] = M[i][j]
-  }
   if (tid == 0) {
     logdet[b] += ld;
     if (bad) flags[b] = 1;
@@ -660,7 +667,9 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
 // products are skipped:
 //   SKIP_UPPER  Bop[kk][c] == 0 unless tile(c) >= chunk(kk)
 //   SKIP_LOWER  Bop[kk][c] == 0 unless tile(c) <= chunk(kk)
-enum { SKIP_NONE = 0, SKIP_UPPER = 1, SKIP_LOWER = 2, SKIP_DIAG = 3 };   // SKIP_DIAG: symmetric result, wave w computes blocks t <= w only
+enum { SKIP_NONE = 0, SKIP_UPPER = 1, SKIP_LOWER = 2, SKIP_DIAG = 3, SKIP_PTP = 4 };   // SKIP_DIAG: symmetric result, wave w computes blocks t <= w only
+// SKIP_PTP: M^T M of the lower block-triangular M (both operands = M, k-major): SKIP_DIAG, and strip w starts at chunk w
+// (block (chunk, w) of M is zero above the diagonal and was never written: k_pivot stores the non-zero blocks only)
 
 // store a wave's 16x112 accumulator strip transposed: dst[(16*t + col) * ld + 16*wave + row] = sign*acc
 // (per-wave 16x17 LDS scratch; the staging buffers must be free)
@@ -726,6 +735,7 @@ template <int SKIP, bool NEG_A>
 __device__ __forceinline__ void chunk_mfma_dma(const double* __restrict__ As, const double* __restrict__ Bs,
                                                v4d acc[NBT], int wave, int lane, int ch) {
   const int lr = lane & 15, lk = lane >> 4;
+  if (SKIP == SKIP_PTP && ch < wave) return;
 #pragma unroll
   for (int ks = 0; ks < KC / 4; ++ks) {
     const int row = (ks * 4 + lk) * NB;
@@ -734,7 +744,7 @@ __device__ __forceinline__ void chunk_mfma_dma(const double* __restrict__ As, co
 #pragma unroll
     for (int t = 0; t < NBT; ++t) {
       if (SKIP == SKIP_LOWER && t > ch) continue;
-      if (SKIP == SKIP_DIAG && t > wave) continue;
+      if ((SKIP == SKIP_DIAG || SKIP == SKIP_PTP) && t > wave) continue;
       const double bv = Bs[row + 16 * t + lr];
       acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
     }
@@ -787,6 +797,120 @@ __device__ __forceinline__ void tile_product_dma_latec(const double* __restrict_
     if (ch + 1 < NB / KC) dma_chunk(Aop, lda, Bop, ldb, ch + 1, nxt, nxt + DMA_CHUNK, wave, lane);
     chunk_mfma_dma<SKIP_NONE, true>(cur, cur + DMA_CHUNK, acc, wave, lane, ch);
   }
+}
+
+// ---------------------------------------------------------------- strip mode (small batches)
+// With a handful of GPs per launch (the reference's warm-start chain: one GP, or one per image) a 7-wave workgroup
+// per 112x112 tile leaves most of the 256 CUs idle and the launch takes as long as ONE tile product on ONE CU.  In
+// strip mode a tile is seven workgroups of ONE wave: each owns a 16-row strip, loads the whole B chunk (14 KB) and
+// only its own 16 x 16 corner of the A chunk (2 KB), and, being alone, needs no barrier -- only s_waitcnt on its own
+// LDS-DMA -- so it prefetches two chunks ahead (three stages of 16 KB).  Same per-strip arithmetic in the same order
+// as the workgroup form: bit-identical results.  B-operand traffic is 7x (L2 hits), irrelevant at these sizes.
+#define SCH (KC * NB + KC * 16)   // doubles per stage: B chunk [16][112] | A strip chunk [16][16]
+#define S_STAGES 3
+
+// ROWMAJOR_A: the A operand lies row-major ([row][kk], the tile below the pivot in k_panel): stored XOR-swizzled as in
+// dma_chunk_panel (unit u of row r at slot 8r + (u ^ ((r>>1)&7))); otherwise k-major ([kk][row]) -> [kk][16].
+template <bool ROWMAJOR_A>
+__device__ __forceinline__ void strip_dma(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop, int ldb,
+                                          int chunk, double* __restrict__ buf, int strip, int lane) {
+  const char* pb = (const char*)(Bop + (size_t)(chunk * KC) * ldb);
+#pragma unroll
+  for (int u = 0; u < 14; ++u) {
+    const int e = u * 128 + lane * 2;
+    const int kk = e / NB, c = e % NB;
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(pb + (unsigned)(kk * ldb + c) * 8u),
+                                     (__attribute__((address_space(3))) void*)(buf + u * 128), 16, 0, 0);
+  }
+  double* bufA = buf + KC * NB;
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int q = u * 8 + (lane >> 3), j = lane & 7;   // q: kk (k-major) or row (row-major); j: 16-byte unit
+    const char* pa;
+    if (!ROWMAJOR_A) pa = (const char*)(Aop + (size_t)(chunk * KC + q) * lda + 16 * strip + 2 * j);
+    else pa = (const char*)(Aop + (size_t)(16 * strip + q) * lda + chunk * KC + 2 * (j ^ ((q >> 1) & 7)));
+    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)pa,
+                                     (__attribute__((address_space(3))) void*)(bufA + u * 128), 16, 0, 0);
+  }
+}
+
+template <int SKIP, bool NEG_A, bool ROWMAJOR_A>
+__device__ __forceinline__ void strip_mfma(const double* __restrict__ buf, v4d acc[NBT], int strip, int lane, int ch) {
+  const int lr = lane & 15, lk = lane >> 4;
+  const double* As = buf + KC * NB;
+  if (SKIP == SKIP_PTP && ch < strip) return;
+#pragma unroll
+  for (int ks = 0; ks < KC / 4; ++ks) {
+    const int kk = ks * 4 + lk;
+    const double a0 = ROWMAJOR_A ? As[(lr * 8 + ((kk >> 1) ^ ((lr >> 1) & 7))) * 2 + (kk & 1)] : As[kk * 16 + lr];
+    const double av = NEG_A ? -a0 : a0;
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) {
+      if (SKIP == SKIP_LOWER && t > ch) continue;
+      if (SKIP == SKIP_UPPER && t < ch) continue;
+      if ((SKIP == SKIP_DIAG || SKIP == SKIP_PTP) && t > strip) continue;
+      const double bv = buf[kk * NB + 16 * t + lr];
+      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+    }
+  }
+}
+
+template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+
+// acc (+)= (+-)A1 B1 [+ (+-)A2 B2]: NPH phases of 7 chunks, one continuous stream.  LATEC: acc starts at zero and the
+// strip of C (Ct, ldc) is loaded behind chunk 0's DMA and added after chunk 0's products (as tile_product_dma_latec).
+// Every strip_dma is 16 LDS-DMA instructions, the 28 loads of C sit between chunk 0's and chunk 1's: waiting for
+// chunk g leaves exactly the instructions issued after it outstanding.
+template <int SKIP1, bool NEG1, int SKIP2, bool NEG2, bool LATEC, int NPH, bool ROWMAJOR_A1>
+__device__ __forceinline__ void strip_product(const double* __restrict__ A1, int lda1, const double* __restrict__ B1, int ldb1,
+                                              const double* __restrict__ A2, int lda2, const double* __restrict__ B2, int ldb2,
+                                              double* __restrict__ lds, v4d acc[NBT], const double* __restrict__ Ct, size_t ldc,
+                                              int strip, int lane) {
+  constexpr int NC = NB / KC, G = NPH * NC;
+  strip_dma<ROWMAJOR_A1>(A1, lda1, B1, ldb1, 0, lds, strip, lane);
+  v4d c0[NBT];
+  if (LATEC) {
+#pragma unroll
+    for (int t = 0; t < NBT; ++t)
+#pragma unroll
+      for (int rr = 0; rr < 4; ++rr) c0[t][rr] = Ct[(size_t)(4 * rr) * ldc + 16 * t];
+#pragma unroll
+    for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  }
+  strip_dma<ROWMAJOR_A1>(A1, lda1, B1, ldb1, 1, lds + SCH, strip, lane);
+#pragma unroll
+  for (int g = 0; g < G; ++g) {
+    double* cur = lds + (g % S_STAGES) * SCH;
+    if (g == 0 && LATEC) wait_vmcnt<16 + 28>();
+    else if (g + 1 < G) wait_vmcnt<16>();
+    else wait_vmcnt<0>();
+    if (g + 2 < G) {   // into the stage read at iteration g-1: its LDS reads were consumed by that iteration's MFMAs
+      double* nxt = lds + ((g + 2) % S_STAGES) * SCH;
+      if (g + 2 < NC) strip_dma<ROWMAJOR_A1>(A1, lda1, B1, ldb1, g + 2, nxt, strip, lane);
+      else strip_dma<false>(A2, lda2, B2, ldb2, g + 2 - NC, nxt, strip, lane);
+    }
+    if (g < NC) strip_mfma<SKIP1, NEG1, ROWMAJOR_A1>(cur, acc, strip, lane, g);
+    else strip_mfma<SKIP2, NEG2, false>(cur, acc, strip, lane, g - NC);
+    if (LATEC && g == 0) {
+#pragma unroll
+      for (int t = 0; t < NBT; ++t) acc[t] += c0[t];
+    }
+  }
+}
+
+// one interface for both forms
+template <int SKIP, bool NEG_A, bool STRIP>
+__device__ __forceinline__ void tile_product(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop, int ldb,
+                                             double* __restrict__ lds, v4d acc[NBT], int wave, int lane) {
+  if constexpr (STRIP) strip_product<SKIP, NEG_A, SKIP_NONE, false, false, 1, false>(Aop, lda, Bop, ldb, nullptr, 0, nullptr, 0, lds, acc, nullptr, 0, wave, lane);
+  else tile_product_dma<SKIP, NEG_A>(Aop, lda, Bop, ldb, lds, acc, wave, lane);
+}
+template <bool STRIP>
+__device__ __forceinline__ void tile_product_latec(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop, int ldb,
+                                                   double* __restrict__ lds, v4d acc[NBT], const double* __restrict__ Ct, size_t ldc,
+                                                   int wave, int lane) {
+  if constexpr (STRIP) strip_product<SKIP_NONE, true, SKIP_NONE, false, true, 1, false>(Aop, lda, Bop, ldb, nullptr, 0, nullptr, 0, lds, acc, Ct, ldc, wave, lane);
+  else tile_product_dma_latec(Aop, lda, Bop, ldb, lds, acc, Ct, ldc, wave, lane);
 }
 
 // ---- alpha = K^-1 (y - c) without re-reading the inverse -------------------------------
@@ -922,22 +1046,61 @@ __device__ __forceinline__ void tile_product_dma2(const double* __restrict__ A1,
 #endif
 }
 
-template <bool G1>   // G1: last pivot step of a fit evaluation, leaves the alpha mat-vec partials (own instantiation:
-                     // the epilogue's registers must not weigh on the six launches that do not need it)
-__global__ void __launch_bounds__(MM_THREADS, 4)
+// tile (k,k) of -A^-1 after pivot step k: -P = -M^T M (what k_pivot's phase 3 computes when asked to)
+template <bool STRIP>
+__device__ __forceinline__ void form_ptile(double* __restrict__ Tkk, const double* __restrict__ M, double* __restrict__ lds,
+                                           int wave, int lane) {
+  const int lr = lane & 15, lk = lane >> 4;
+  v4d acc[NBT];
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  tile_product<SKIP_PTP, true, STRIP>(M, NB, M, NB, lds, acc, wave, lane);
+  double* Ct = Tkk + (size_t)(16 * wave + lk) * NB + lr;
+#pragma unroll
+  for (int t = 0; t < NBT; ++t) {
+    if (t > wave) break;
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
+  }
+  __syncthreads();
+  store_strip_transposed(acc, Tkk, (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
+}
+
+template <int SKIP1, bool NEG1, int SKIP2, bool NEG2, bool LATEC, bool STRIP>
+__device__ __forceinline__ void tile_product2(const double* __restrict__ A1, int lda1, const double* __restrict__ B1, int ldb1,
+                                              const double* __restrict__ A2, int lda2, const double* __restrict__ B2, int ldb2,
+                                              double* __restrict__ lds, v4d acc[NBT], const double* __restrict__ Ct, size_t ldc,
+                                              int wave, int lane) {
+  if constexpr (STRIP) strip_product<SKIP1, NEG1, SKIP2, NEG2, LATEC, 2, false>(A1, lda1, B1, ldb1, A2, lda2, B2, ldb2, lds, acc, Ct, ldc, wave, lane);
+  else tile_product_dma2<SKIP1, NEG1, SKIP2, NEG2, LATEC>(A1, lda1, B1, ldb1, A2, lda2, B2, ldb2, lds, acc, Ct, ldc, wave, lane);
+}
+
+template <bool G1, bool STRIP>   // G1: last pivot step of a fit evaluation, leaves the alpha mat-vec partials (own
+                     // instantiation: the epilogue's registers must not weigh on the six launches that do not need it).
+                     // STRIP: one wave per workgroup, seven workgroups per tile (small batches; never with G1)
+__global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
 k_update(double* __restrict__ A, int N, int nblk, int k,
              const double* __restrict__ Wo, const double* __restrict__ Mbuf, int ntri1, int total,
              const double* __restrict__ y, const float* __restrict__ raw, int n, double* __restrict__ part,
-             int sel) {
+             int sel, int ptile) {   // ptile (sel < 0, never with G1): one more tile per GP, (k,k) = -M^T M
+  static_assert(!(G1 && STRIP), "the alpha epilogue reduces across the waves of a workgroup");
   __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-  const int v = xcd_remap(blockIdx.x, total);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int vv = xcd_remap(blockIdx.x, total);
+  const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int v = STRIP ? vv / NBT : vv;
   // sel < 0: every tile of the step.  sel >= 0 (first half of a two-pivot step): only the nblk tiles that
   // the NEXT pivot's panel reads, i.e. those of block row / column `sel`: the nblk-1 trailing tiles
   // (sel, other) / (other, sel) and the pivot-column tile of row block sel.
-  const int per = sel < 0 ? ntri1 + nblk - 1 : nblk;
+  const int per = sel < 0 ? ntri1 + nblk - 1 + ptile : nblk;
   const int b = v / per, t0 = v % per;
   double* Ab = A + (size_t)b * N * N;
+  if constexpr (!G1) {
+    if (sel < 0 && t0 == ntri1 + nblk - 1) {
+      form_ptile<STRIP>(Ab + TILE_OFF(k, k, nblk), Mbuf + (size_t)b * NB * NB, lds, wave, lane);
+      return;
+    }
+  }
   const int lr = lane & 15, lk = lane >> 4;
   v4d acc[NBT];
   __shared__ double rv[2 * NB];   // G1 only: r = y - c of the tile's row and column blocks
@@ -963,7 +1126,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * NB + 16 * t] : 0.0;
-      tile_product_dma<SKIP_DIAG, true>(Aop, NB, Bop, NB, lds, acc, wave, lane);
+      tile_product<SKIP_DIAG, true, STRIP>(Aop, NB, Bop, NB, lds, acc, wave, lane);
 #pragma unroll
       for (int t = 0; t < NBT; ++t) {
         if (t > wave) break;
@@ -974,7 +1137,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
       store_strip_transposed(acc, Ab + TILE_OFF(I, I, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
       if (G1) grad1_partials(acc, true, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
     } else {
-      tile_product_dma_latec(Aop, NB, Bop, NB, lds, acc, Ct, (size_t)NB, wave, lane);
+      tile_product_latec<STRIP>(Aop, NB, Bop, NB, lds, acc, Ct, (size_t)NB, wave, lane);
 #pragma unroll
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
@@ -990,7 +1153,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
     const double* Bop = Mbuf + (size_t)b * NB * NB;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_product_dma<SKIP_LOWER, false>(Aop, NB, Bop, NB, lds, acc, wave, lane);
+    tile_product<SKIP_LOWER, false, STRIP>(Aop, NB, Bop, NB, lds, acc, wave, lane);
     if (I > k) {
       double* Ct = Ab + TILE_OFF(I, k, nblk) + (size_t)(16 * wave + lk) * NB + lr;
 #pragma unroll
@@ -1014,22 +1177,26 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
 // pass over A (k-depth 224: C is read and written once instead of twice):
 //   (a) trailing (I,J), I,J not in {k1,k2}:  A_IJ  -= W1_I W1_J^T + W2_I W2_J^T
 //   (b) I not in {k1,k2}:                    A_Ik1  = W1_I M1 - W2_I W2_k1^T   (pivot column of step k1, then trailing of k2)
-//   (c) tile (k1,k1) (= -P1 from pivot k1):  A_k1k1 -= W2_k1 W2_k1^T
+//   (c) tile (k1,k1) (= -P1 from pivot k1):  A_k1k1 -= W2_k1 W2_k1^T;  with ptile (c'): A_k1k1 = -M1^T M1 - W2_k1 W2_k1^T
 //   (d) I != k2:                             A_Ik2  = W2_I M2                  (pivot column of step k2)
-// grid.x = (ntri(nblk-2) + (nblk-2) + 1 + (nblk-1)) * B.
-__global__ void __launch_bounds__(MM_THREADS, 4)
+//   (e) tile (k2,k2), with ptile:            A_k2k2 = -M2^T M2
+// grid.x = (ntri(nblk-2) + (nblk-2) + 1 + (nblk-1) + ptile) * B.
+template <bool STRIP>
+__global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
 k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restrict__ Wo1,
           const double* __restrict__ Wo2, const double* __restrict__ M1buf, const double* __restrict__ M2buf,
-          int total) {
+          int total, int ptile) {   // ptile: the pivots left tiles (k1,k1), (k2,k2) to this launch (roles (c'), (e))
   __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int vv = xcd_remap(blockIdx.x, total);
+  const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
 #ifdef GPSR_UPD_TRACE
   const unsigned long long trc_t0 = TRC_CLK();
 #endif
   const int lr = lane & 15, lk = lane >> 4;
-  const int v = xcd_remap(blockIdx.x, total);
+  const int v = STRIP ? vv / NBT : vv;
   const int k2 = k1 + 1, nb2 = nblk - 2, ntri2 = nb2 * (nb2 + 1) / 2;
-  const int per = ntri2 + nb2 + 1 + nblk - 1;
+  const int per = ntri2 + nb2 + 1 + nblk - 1 + ptile;
   const int b = v / per, t0 = v % per;
   double* Ab = A + (size_t)b * N * N;
   const double* W1 = Wo1 + (size_t)b * NB * N;
@@ -1046,8 +1213,8 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
       for (int t = 0; t < NBT; ++t)
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * NB + 16 * t] : 0.0;
-      tile_product_dma2<SKIP_DIAG, true, SKIP_DIAG, true, false>(W1 + WT(I), NB, W1 + WT(J), NB, W2 + WT(I), NB,
-                                                                 W2 + WT(J), NB, lds, acc, Ct, (size_t)NB, wave, lane);
+      tile_product2<SKIP_DIAG, true, SKIP_DIAG, true, false, STRIP>(W1 + WT(I), NB, W1 + WT(J), NB, W2 + WT(I), NB,
+                                                                    W2 + WT(J), NB, lds, acc, Ct, (size_t)NB, wave, lane);
 #pragma unroll
       for (int t = 0; t < NBT; ++t) {
         if (t > wave) break;
@@ -1060,8 +1227,8 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
 #ifdef GPSR_UPD_TRACE
       const unsigned long long trc_t1 = TRC_CLK();
 #endif
-      tile_product_dma2<SKIP_NONE, true, SKIP_NONE, true, true>(W1 + WT(I), NB, W1 + WT(J), NB, W2 + WT(I), NB,
-                                                                W2 + WT(J), NB, lds, acc, Ct, (size_t)NB, wave, lane);
+      tile_product2<SKIP_NONE, true, SKIP_NONE, true, true, STRIP>(W1 + WT(I), NB, W1 + WT(J), NB, W2 + WT(I), NB,
+                                                                   W2 + WT(J), NB, lds, acc, Ct, (size_t)NB, wave, lane);
 #ifdef GPSR_UPD_TRACE
       const unsigned long long trc_t2 = TRC_CLK();
 #endif
@@ -1084,9 +1251,9 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
     int I = t0 - ntri2; if (I >= k1) I += 2;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_product_dma2<SKIP_LOWER, false, SKIP_NONE, true, false>(W1 + WT(I), NB, M1buf + (size_t)b * NB * NB, NB,
-                                                                 W2 + WT(I), NB, W2 + WT(k1), NB, lds, acc, nullptr,
-                                                                 0, wave, lane);
+    tile_product2<SKIP_LOWER, false, SKIP_NONE, true, false, STRIP>(W1 + WT(I), NB, M1buf + (size_t)b * NB * NB, NB,
+                                                                    W2 + WT(I), NB, W2 + WT(k1), NB, lds, acc, nullptr,
+                                                                    0, wave, lane);
     if (I > k1) {
       double* Ct = Ab + TILE_OFF(I, k1, nblk) + (size_t)(16 * wave + lk) * NB + lr;
 #pragma unroll
@@ -1099,11 +1266,19 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
     }
   } else if (t0 == ntri2 + nb2) {                     // (c)
     double* Ct = Ab + TILE_OFF(k1, k1, nblk) + (size_t)(16 * wave + lk) * NB + lr;
+    if (ptile) {
 #pragma unroll
-    for (int t = 0; t < NBT; ++t)
+      for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+      const double* M1 = M1buf + (size_t)b * NB * NB;
+      tile_product2<SKIP_PTP, true, SKIP_DIAG, true, false, STRIP>(M1, NB, M1, NB, W2 + WT(k1), NB, W2 + WT(k1), NB, lds, acc,
+                                                                   nullptr, 0, wave, lane);
+    } else {   // -P1 is there (k_pivot with_p)
 #pragma unroll
-      for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * NB + 16 * t] : 0.0;
-    tile_product_dma<SKIP_DIAG, true>(W2 + WT(k1), NB, W2 + WT(k1), NB, lds, acc, wave, lane);
+      for (int t = 0; t < NBT; ++t)
+#pragma unroll
+        for (int rr = 0; rr < 4; ++rr) acc[t][rr] = t <= wave ? Ct[(size_t)(4 * rr) * NB + 16 * t] : 0.0;
+      tile_product<SKIP_DIAG, true, STRIP>(W2 + WT(k1), NB, W2 + WT(k1), NB, lds, acc, wave, lane);
+    }
 #pragma unroll
     for (int t = 0; t < NBT; ++t) {
       if (t > wave) break;
@@ -1112,11 +1287,13 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
     }
     __syncthreads();
     store_strip_transposed(acc, Ab + TILE_OFF(k1, k1, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
+  } else if (ptile && t0 == per - 1) {                // (e)
+    form_ptile<STRIP>(Ab + TILE_OFF(k2, k2, nblk), M2buf + (size_t)b * NB * NB, lds, wave, lane);
   } else {                                            // (d)
     int I = t0 - (ntri2 + nb2 + 1); if (I >= k2) ++I;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_product_dma<SKIP_LOWER, false>(W2 + WT(I), NB, M2buf + (size_t)b * NB * NB, NB, lds, acc, wave, lane);
+    tile_product<SKIP_LOWER, false, STRIP>(W2 + WT(I), NB, M2buf + (size_t)b * NB * NB, NB, lds, acc, wave, lane);
     if (I > k2) {
       double* Ct = Ab + TILE_OFF(I, k2, nblk) + (size_t)(16 * wave + lk) * NB + lr;
 #pragma unroll
@@ -1169,13 +1346,16 @@ __device__ __forceinline__ void dma_chunk_panel(const double* __restrict__ Tsrc,
   }
 }
 
-__global__ void __launch_bounds__(MM_THREADS, 4)
+template <bool STRIP>
+__global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
 k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Ubuf,
          double* __restrict__ Wo, int total) {
   __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
-  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int tid = threadIdx.x, lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
-  const int v = xcd_remap(blockIdx.x, total);
+  const int vv = xcd_remap(blockIdx.x, total);
+  const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int v = STRIP ? vv / NBT : vv;
   const int b = v / (nblk - 1);
   int i = v % (nblk - 1); if (i >= k) ++i;
   const double* Ab = A + (size_t)b * N * N;
@@ -1186,6 +1366,10 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
   v4d acc[NBT];
 #pragma unroll
   for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+  if constexpr (STRIP) {
+    if (below) strip_product<SKIP_UPPER, false, SKIP_NONE, false, false, 1, true>(Tsrc, NB, U, NB, nullptr, 0, nullptr, 0, lds, acc, nullptr, 0, wave, lane);
+    else strip_product<SKIP_UPPER, false, SKIP_NONE, false, false, 1, false>(Tsrc, NB, U, NB, nullptr, 0, nullptr, 0, lds, acc, nullptr, 0, wave, lane);
+  } else {
   dma_chunk_panel(Tsrc, (size_t)NB, below, U, 0, lds, lds + DMA_CHUNK, wave, lane);
   const int r = 16 * wave + lr, rsw = (r >> 1) & 7;
 #pragma unroll
@@ -1207,6 +1391,7 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
         acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
       }
     }
+  }
   }
   __syncthreads();
   // acc[t][rr] = W[r = 16*wave + lk + 4rr][k' = 16t + lr]  ->  Wo[k'][i0 + r]

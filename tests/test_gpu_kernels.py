@@ -237,6 +237,38 @@ def test_fit_constant_patch_rbf():
         assert (pred - 0.5).abs().max().item() < 1e-6
 
 
+@pytest.mark.parametrize("n,small", [(784, 1), (784, 4), (324, 3), (1120, 2), (200, 4)])
+def test_small_batch_strip_mode_bit_identical(n, small):
+    """Small batches run the tile products one wave per workgroup, seven workgroups per tile (strip mode), and leave
+    tile (k,k) = -M^T M of a pivot step to the update launch: the arithmetic and its order are those of the large-batch
+    route, so a GP fitted alone gives the same bits as the same GP inside a large batch.  Also the plain inversion."""
+    from super_resolution_amd import ops
+    # large enough that the big batch takes the other route everywhere: workgroup-form tile products, and tile (k,k) of
+    # each pivot step formed by k_pivot itself instead of by the update launch (update_forms_ptile in gpsr_api.hip)
+    B = {784: 24, 324: 96, 1120: 12, 200: 180}[n]
+    rng = np.random.default_rng(n + small)
+    X = to_dev(rng.random((B, n, 8)))
+    y = to_dev(rng.random((B, n)))
+    raw0 = ops.init_hypers(y, ops.MATERN52)
+    raw_b = raw0.clone()
+    alpha_b, flags_b, loss_b = ops.fit(X, y, ops.MATERN52, raw_b, iters=4, want_loss=True)
+    raw_s = raw0[:small].clone()
+    alpha_s, flags_s, loss_s = ops.fit(X[:small].contiguous(), y[:small].contiguous(), ops.MATERN52, raw_s, iters=4, want_loss=True)
+    assert int(flags_b.sum()) == 0 and int(flags_s.sum()) == 0
+    assert torch.equal(alpha_s, alpha_b[:small]) and torch.equal(raw_s, raw_b[:small]) and torch.equal(loss_s, loss_b[:small])
+    N = -(-n // 112) * 112
+    A = np.zeros((B, N, N))
+    for b in range(B):
+        Q = rng.normal(size=(N, N + 8))
+        A[b] = Q @ Q.T / N + 0.05 * np.eye(N)
+    Ab, As = to_dev(A), to_dev(A[:small])
+    ld_b, _ = ops.invert_(Ab)
+    ld_s, _ = ops.invert_(As)
+    assert torch.equal(ld_s, ld_b[:small])
+    for b in range(small):   # the lower block triangle is the result; the rest is scratch
+        assert np.array_equal(_lower_blocks_to_full(As[b].cpu().numpy()), _lower_blocks_to_full(Ab[b].cpu().numpy()))
+
+
 def test_fit_dual_stream_bit_identical():
     """gpsr_set_dual_stream: the batch as two half-batches on two streams gives the same bits
     (per-GP arithmetic does not depend on the batch it runs in)."""
