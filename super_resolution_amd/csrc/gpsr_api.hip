@@ -1039,4 +1039,11 @@ extern "C" int gpsr_debug_piv_trace(unsigned long long* out8) {
   e = hipMemcpyToSymbol(HIP_SYMBOL(g_piv_trace), z, sizeof(z));
   return e == hipSuccess ? 0 : hip_fail(e, "trace clear");
 }
+extern "C" int gpsr_debug_piv_trace2(unsigned long long* out8) {
+  hipError_t e = hipMemcpyFromSymbol(out8, HIP_SYMBOL(g_piv_trace2), 8 * sizeof(unsigned long long));
+  if (e != hipSuccess) return hip_fail(e, "trace2 read");
+  unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  e = hipMemcpyToSymbol(HIP_SYMBOL(g_piv_trace2), z, sizeof(z));
+  return e == hipSuccess ? 0 : hip_fail(e, "trace2 clear");
+}
 #endif

@@ -356,8 +356,7 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
 //   phase 1  blocked Cholesky S = L L^T (16x16 sub-blocks; every wave factors the
 //            16x16 diagonal sub-block redundantly in registers, so inv(L16)^T is at
 //            hand as the B operand of the sub-panel product with no LDS hand-off)
-//   phase 2  M = L^-1 by block forward substitution (wave q owns column block q);
-//            M^T =: U is kept in the (otherwise unused) strictly-upper blocks of S
+//   phase 2  M = L^-1 by block forward substitution, one block column per wave, in registers
 //   phase 3  P = M^T M = U U^T  ->  A_kk <- -P   (the pivot block of -A^-1; with_p, else left to the update launch)
 //   U and M go to global for the panel / update kernels block by block, as each becomes final.
 // Everything outside the 16x16 register kernels is f64 MFMA.  Cholesky form on both
@@ -381,8 +380,7 @@ __device__ __forceinline__ double bcast_lane(double v, int l) {
 // 16x16 SPD block in registers, accumulator lane layout (lr = lane&15, lk = lane>>4; a[c] = D[lk+4c][lr]):
 // m <- inv(chol(D)) in the same layout, *ld += log det D, *bad on a non-positive pivot.  Four columns per step:
 // the k-depth of v_mfma_f64_16x16x4_f64 is 4, so the rank-4 elimination of the block is ONE instruction and no
-// cross-lane shuffle is needed (the column-by-column version of round 1 spent seven ds_bpermute per column; this one
-// is 2-4 % faster per pivot launch: the serial chain is the 4x4 scalar factorisation either way).  Step J (columns 4J..4J+3),
+// cross-lane shuffle is needed.  Step J (columns 4J..4J+3),
 // D = current Schur complement (symmetric, accumulator layout a[c](lr,lk) = D[lk+4c][lr]), M accumulates L^-1:
 //     L4 = chol(D_JJ), M4 = L4^-1        4x4 on ten values broadcast through scalar registers, every lane the same
 //     P  = D[:, 4J..4J+3] M4^T           (16 x 4)  one MFMA: A operand = M4 (lanes lr < 4), B operand = a[J], which
@@ -390,6 +388,13 @@ __device__ __forceinline__ double bcast_lane(double v, int l) {
 //                                        A/B-operand layout (lane (lr,lk) = P[lr][lk])
 //     R  = M4 M[4J..4J+3, :]             (4 x 16)  one MFMA: A = M4, B = m[J]; these are the final rows of M
 //     D -= P P^T ;  M[rows > 4J+3, :] -= P R                                     one MFMA each
+// This is the serial chain of k_pivot (7 calls, 65 % of the workgroup's time), and it is bound by the NUMBER of f64
+// instructions of its one wave, not by their dependences (tools/chol16_bench.hip + tools/valu_lat.hip: a lone wave
+// issues one f64 VALU instruction per ~7.5 cycles dependent or not, v_rsq_f64 ~17, an MFMA 64, and MFMA and f64 VALU
+// share the pipe): per step ~75 f64 instructions + 4 rsq + 20 readlane + 20 cndmask + 4 MFMA = ~1000 cycles.  Hence
+// the 2x2-minor form below (fewer instructions than four sequential pivots), selects instead of a branch tree for the
+// A operand, one log per block: 4896 -> 4032 cycles per call.  Forcing the Schur update ahead of the R product
+// (sched_barrier, or a false dependence) made it slower: 4312 / 4448.
 __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, double* ld, int* bad) {
   const int lr = lane & 15, lk = lane >> 4;
   v4d D = (v4d){a[0], a[1], a[2], a[3]};
@@ -398,43 +403,51 @@ __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, d
   for (int c = 0; c < 4; ++c) M[c] = (lk + 4 * c == lr) ? 1.0 : 0.0;
   double prod = 1.0;
   const v4d zero4 = (v4d){0.0, 0.0, 0.0, 0.0};
+  // the ten lanes (lr + 16 lk, lk <= lr < 4) that carry M4 as the A operand of the P / R products
+  const bool L00 = lane == 0, L10 = lane == 1, L20 = lane == 2, L30 = lane == 3, L11 = lane == 17, L21 = lane == 18,
+             L31 = lane == 19, L22 = lane == 34, L32 = lane == 35, L33 = lane == 51;
 #pragma unroll
   for (int J = 0; J < 4; ++J) {
     // D[4J+r][4J+c] sits in D[J] at lane (lr = 4J+c, lk = r)
     const double dj = D[J];
 #define DJ(r, c) bcast_lane(dj, 4 * J + (c) + 16 * (r))
-    const double d00 = DJ(0, 0);
-    const double r0 = rsqrt_pos(d00);
-    const double l10 = DJ(1, 0) * r0, l20 = DJ(2, 0) * r0, l30 = DJ(3, 0) * r0;
-    const double p1 = fma(-l10, l10, DJ(1, 1));
-    const double r1 = rsqrt_pos(p1);
-    const double l21 = fma(-l20, l10, DJ(2, 1)) * r1, l31 = fma(-l30, l10, DJ(3, 1)) * r1;
-    const double p2 = fma(-l21, l21, fma(-l20, l20, DJ(2, 2)));
-    const double r2 = rsqrt_pos(p2);
-    const double l32 = fma(-l31, l21, fma(-l30, l20, DJ(3, 2))) * r2;
-    const double p3 = fma(-l32, l32, fma(-l31, l31, fma(-l30, l30, DJ(3, 3))));
-    const double r3 = rsqrt_pos(p3);
+    const double d00 = DJ(0, 0), d10 = DJ(1, 0), d11 = DJ(1, 1), d20 = DJ(2, 0), d21 = DJ(2, 1), d22 = DJ(2, 2),
+                 d30 = DJ(3, 0), d31 = DJ(3, 1), d32 = DJ(3, 2), d33 = DJ(3, 3);
 #undef DJ
-    if (!(d00 > 0.0) || !(p1 > 0.0) || !(p2 > 0.0) || !(p3 > 0.0)) *bad = 1;
-    prod *= (d00 * p1) * (p2 * p3);     // 16 pivots in [1e-4, 1e3]: no over/underflow; one log per block
+    // The 4x4 block as two 2x2 blocks.  Second pivot of a 2x2 block [[x, y], [y, z]]: p = z - y^2/x = q/x with the minor
+    // q = x z - y^2, so 1/sqrt(p) = sqrt(x) / sqrt(q): the two v_rsq_f64 + correction chains run side by side instead of
+    // one after the other (the rounding error of q is eps (xz + y^2), i.e. eps (z + y^2/x) on p: that of the usual form).
+    const double q1 = fma(-d10, d10, d00 * d11);
+    const double r0 = rsqrt_pos(d00), rq1 = rsqrt_pos(q1);
+    const double r1 = rq1 * (d00 * r0);
+    const double l10 = d10 * r0, l20 = d20 * r0, l30 = d30 * r0;
+    const double l21 = fma(-l20, l10, d21) * r1, l31 = fma(-l30, l10, d31) * r1;
+    const double e22 = fma(-l21, l21, fma(-l20, l20, d22));
+    const double e32 = fma(-l31, l21, fma(-l30, l20, d32));
+    const double e33 = fma(-l31, l31, fma(-l30, l30, d33));
+    const double q3 = fma(-e32, e32, e22 * e33);
+    const double r2 = rsqrt_pos(e22), rq3 = rsqrt_pos(q3);
+    const double r3 = rq3 * (e22 * r2);
+    const double l32 = e32 * r2;
+    if (!(d00 > 0.0) || !(q1 > 0.0) || !(e22 > 0.0) || !(q3 > 0.0)) *bad = 1;
+    prod *= q1 * q3;                    // = the four pivots d00 (q1/d00) e22 (q3/e22); 16 pivots in [1e-4, 1e3]: one log per block
     const double m10 = -(l10 * r0) * r1;
     const double m21 = -(l21 * r1) * r2;
     const double m32 = -(l32 * r2) * r3;
     const double m20 = -fma(l21, m10, l20 * r0) * r2;
     const double m31 = -fma(l32, m21, l31 * r1) * r3;
     const double m30 = -fma(l32, m20, fma(l31, m10, l30 * r0)) * r3;
-    // A operand of the P / R products: lane (lr, lk) holds M4[lr][lk] for lr < 4, zero elsewhere
-    double m4a = 0.0;
-    if (lr == 0) m4a = (lk == 0) ? r0 : 0.0;
-    else if (lr == 1) m4a = (lk == 0) ? m10 : (lk == 1 ? r1 : 0.0);
-    else if (lr == 2) m4a = (lk == 0) ? m20 : (lk == 1 ? m21 : (lk == 2 ? r2 : 0.0));
-    else if (lr == 3) m4a = (lk == 0) ? m30 : (lk == 1 ? m31 : (lk == 2 ? m32 : r3));
+    // A operand of the P / R products: lane (lr, lk) holds M4[lr][lk] for lr < 4, zero elsewhere (selects, no branches)
+    double m4a = L00 ? r0 : 0.0;
+    m4a = L10 ? m10 : m4a; m4a = L11 ? r1 : m4a;
+    m4a = L20 ? m20 : m4a; m4a = L21 ? m21 : m4a; m4a = L22 ? r2 : m4a;
+    m4a = L30 ? m30 : m4a; m4a = L31 ? m31 : m4a; m4a = L32 ? m32 : m4a; m4a = L33 ? r3 : m4a;
     const v4d po = __builtin_amdgcn_mfma_f64_16x16x4f64(m4a, D[J], zero4, 0, 0, 0);
-    const v4d ro = __builtin_amdgcn_mfma_f64_16x16x4f64(m4a, M[J], zero4, 0, 0, 0);
     const double P = (lr < 4 * J) ? 0.0 : po[0];          // rows of blocks already eliminated contribute nothing
     const double Pm = (lr < 4 * J + 4) ? 0.0 : po[0];     // only rows below the block are eliminated in M
-    const double R = ro[0];
     if (J < 3) D = __builtin_amdgcn_mfma_f64_16x16x4f64(-P, P, D, 0, 0, 0);
+    const v4d ro = __builtin_amdgcn_mfma_f64_16x16x4f64(m4a, M[J], zero4, 0, 0, 0);
+    const double R = ro[0];
     M = __builtin_amdgcn_mfma_f64_16x16x4f64(-Pm, R, M, 0, 0, 0);
     M[J] = R;                                             // rows 4J..4J+3 of M are final
   }
@@ -444,8 +457,7 @@ __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, d
 }
 
 // Block-packed LDS image of the pivot block: the 28 lower 16x16 blocks, each [16][17];
-// (i,j), i >= j, at block index i(i+1)/2 + j.  60.9 KB + 15.2 KB of per-wave transpose
-// scratch = 76 KB -> two workgroups per CU (the 16x16 register factorisations are a serial,
+// (i,j), i >= j, at block index i(i+1)/2 + j.  60.9 KB -> two workgroups per CU (the 16x16 register factorisations are a serial,
 // latency-bound chain: a second resident workgroup fills the bubbles).
 #define PV_BLK (16 * PV_DLD)
 #define PV_NBLK (NBT * (NBT + 1) / 2)
@@ -456,6 +468,12 @@ __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, d
 // thread 0 right after the barrier that ends each phase): [0] workgroups, [1] load, [2] blocked Cholesky,
 // [3] M = L^-1, [4] P = M^T M + stores of A_kk, [5] U / M stores, [6] entry -> exit.
 __device__ unsigned long long g_piv_trace[8];
+// g_piv_trace2: the look-ahead (critical) wave q+1 inside step q of phase 1, summed over steps and workgroups:
+// [0] steps, [1] sub-panel product, [2] wait at the barrier after it, [3] diagonal block update, [4] chol16_inv + publish,
+// [5] wait at the step's last barrier, [6] wave 6's trailing update (steps where it is not the look-ahead wave), [7] its count
+__device__ unsigned long long g_piv_trace2[8];
+#define PIV2_T() __builtin_readcyclecounter()
+#define PIV2_ADD(i, v) do { if (lane == 0) atomicAdd(&g_piv_trace2[i], (unsigned long long)(v)); } while (0)
 #define PIV_STAMP(i) do { if (tid == 0) { const unsigned long long t_ = __builtin_readcyclecounter(); atomicAdd(&g_piv_trace[i], t_ - piv_t); piv_t = t_; } } while (0)
 #else
 #define PIV_STAMP(i)
@@ -483,7 +501,6 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   const unsigned long long piv_t0 = piv_t;
 #endif
   double* S = sm;                           // [PV_NBLK][16][PV_DLD]
-  double* Tr = sm + PV_NBLK * PV_BLK;       // [NBT waves][16][PV_DLD] per-wave transpose scratch
   const int b = blockIdx.x, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   double* Akk = A + (size_t)b * N * N + TILE_OFF(k, k, N / NB);   // the pivot tile: contiguous [NB][NB]
@@ -509,7 +526,6 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   PIV_STAMP(1);
   double ld = 0.0;
   int bad = 0;
-  double* tr = Tr + wave * PV_BLK;
   double* Ub = Ubuf + (size_t)b * NB * NB;
   double* Mb = Mbuf + (size_t)b * NB * NB;
   // ---------------- phase 1: blocked Cholesky; afterwards SB(q,q) = inv(L16_q), SB(w,q) = L[w,q]
@@ -529,6 +545,10 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   }
   __syncthreads();
   for (int q = 0; q < NBT - 1; ++q) {
+#ifdef GPSR_PIV_TRACE
+    const bool crit = wave == q + 1;
+    unsigned long long p2a = PIV2_T(), p2b = 0, p2c = 0, p2d = 0, p2e = 0;
+#endif
     if (wave > q) {
       // L_wq = S[w,q] * inv(L16)^T : B operand element (k, col) = inv(L16)[col][k]
       const double* Mqq = SB(q, q);
@@ -542,7 +562,13 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
 #pragma unroll
       for (int c = 0; c < 4; ++c) Swq[(lk + 4 * c) * PV_DLD + lr] = cw[c];
     }
+#ifdef GPSR_PIV_TRACE
+    p2b = PIV2_T();
+#endif
     __syncthreads();   // panel column q written
+#ifdef GPSR_PIV_TRACE
+    p2c = PIV2_T();
+#endif
     if (wave > q) {
       const double* Swq = SB(wave, q);
       double an[4];
@@ -558,6 +584,10 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
         for (int ks = 0; ks < 4; ++ks)
           acc = __builtin_amdgcn_mfma_f64_16x16x4f64(an[ks], Sjq[lr * PV_DLD + lk + 4 * ks], acc, 0, 0, 0);
         if (wave == q + 1) {   // j == wave: the next diagonal block, final -> factor it now
+#ifdef GPSR_PIV_TRACE
+          asm volatile("s_nop 0" :: "v"(acc[0]), "v"(acc[3]));
+          p2d = PIV2_T();
+#endif
           double a[4], m[4];
 #pragma unroll
           for (int c = 0; c < 4; ++c) a[c] = acc[c];
@@ -571,7 +601,20 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
         }
       }
     }
+#ifdef GPSR_PIV_TRACE
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    p2e = PIV2_T();
+#endif
     __syncthreads();
+#ifdef GPSR_PIV_TRACE
+    {
+      const unsigned long long p2f = PIV2_T();
+      if (crit) {
+        PIV2_ADD(0, 1); PIV2_ADD(1, p2b - p2a); PIV2_ADD(2, p2c - p2b); PIV2_ADD(3, p2d - p2c); PIV2_ADD(4, p2e - p2d);
+        PIV2_ADD(5, p2f - p2e);
+      } else if (wave == NBT - 1) { PIV2_ADD(6, p2e - p2c); PIV2_ADD(7, 1); }
+    }
+#endif
   }
   PIV_STAMP(2);
   // every wave factored one diagonal block: combine log-determinant and flags
@@ -585,40 +628,58 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
       for (int w = 0; w < NBT; ++w) { ld += ldsum[w]; bad |= badsum[w]; }
     }
   }
-  // ---------------- phase 2: M = L^-1 in place, block columns from right to left:
-  //   M[w,q] = -(sum_{t=q+1..w} M[w,t] L[t,q]) inv(L16_q),   w > q
-  for (int q = NBT - 2; q >= 0; --q) {
-    v4d res = (v4d){0.0, 0.0, 0.0, 0.0};
-    if (wave > q) {
-      v4d acc = (v4d){0.0, 0.0, 0.0, 0.0};
-      for (int t = q + 1; t <= wave; ++t) {
-        const double* Mwt = SB(wave, t);   // t == wave: inv(L16_w)
-        const double* Ltq = SB(t, q);
+  // ---------------- phase 2: M = L^-1, one block COLUMN per wave, no barrier: column q of M solves L X = E_q by forward
+  // substitution down the rows,
+  //   X[q] = inv(L16_q),   X[w] = -inv(L16_w) * sum_{t=q..w-1} L[w,t] X[t],   w = q+1 .. 6,
+  // and needs nothing from the other columns.  X stays in registers in accumulator layout (reg c of lane (lr,lk) =
+  // X[lk+4c][lr]), which IS the MFMA B-operand layout once the k index is read as lk+4c instead of 4ks+lk -- the A
+  // operand (L[w,t] resp. inv(L16_w), from LDS) is simply indexed the same way -- so there is no transposition and no
+  // LDS write; L stays intact for the other waves, and every finished block goes straight to global (M and U = M^T).
+  // Column q costs (7-q)(8-q)/2 - 1 block products: 27, 20, 14, 9, 5, 2, 0.  Waves w and w+4 share a SIMD, so the
+  // columns are dealt 1,2,3,0 | 6,5,4: column 0 has a SIMD to itself, the others pair up to 20 / 16 / 14.
+  // (The right-to-left in-place form this replaces took two barriers and an LDS transposition per block column:
+  // 18.1 k of the workgroup's 75.6 k cycles, for 6.9 k cycles of MFMA time on its busiest wave.)
+  {
+    const int col = wave < 4 ? (wave + 1) & 3 : 10 - wave;
+    v4d X[NBT];
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
-          acc = __builtin_amdgcn_mfma_f64_16x16x4f64(Mwt[lr * PV_DLD + lk + 4 * ks], Ltq[(lk + 4 * ks) * PV_DLD + lr],
-                                                     acc, 0, 0, 0);
+    for (int t = 0; t < NBT; ++t) {
+      if (t == col) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) X[t][c] = SB(t, t)[(lk + 4 * c) * PV_DLD + lr];
+      } else X[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    }
+#pragma unroll
+    for (int w = 1; w < NBT; ++w) {
+      if (w <= col) continue;
+      v4d sum = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+      for (int t = 0; t < w; ++t) {
+        if (t < col) continue;
+        const double* Lwt = SB(w, t);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          sum = __builtin_amdgcn_mfma_f64_16x16x4f64(Lwt[lr * PV_DLD + lk + 4 * c], X[t][c], sum, 0, 0, 0);
       }
-      // acc (C/D layout) as the A operand of acc * inv(L16_q): transpose through the scratch
+      const double* Mww = SB(w, w);
+      v4d xw = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
-      for (int c = 0; c < 4; ++c) tr[(lk + 4 * c) * PV_DLD + lr] = -acc[c];
-      __builtin_amdgcn_wave_barrier();
-      const double* Mqq = SB(q, q);
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks)
-        res = __builtin_amdgcn_mfma_f64_16x16x4f64(tr[lr * PV_DLD + lk + 4 * ks], Mqq[(lk + 4 * ks) * PV_DLD + lr],
-                                                   res, 0, 0, 0);
-      __builtin_amdgcn_wave_barrier();
+      for (int c = 0; c < 4; ++c)
+        xw = __builtin_amdgcn_mfma_f64_16x16x4f64(-Mww[lr * PV_DLD + lk + 4 * c], sum[c], xw, 0, 0, 0);
+      X[w] = xw;
+      const double xv[4] = {xw[0], xw[1], xw[2], xw[3]};
+      store_mu_block(Mb, Ub, w, col, xv, lr, lk);
     }
-    __syncthreads();   // all reads of L[.,q] done
-    if (wave > q) {
-      double* Swq = SB(wave, q);
+    if (with_p) {   // phase 3 reads M from LDS: in place of L, once every wave is done reading L
+      __syncthreads();
 #pragma unroll
-      for (int c = 0; c < 4; ++c) Swq[(lk + 4 * c) * PV_DLD + lr] = res[c];
-      const double rv[4] = {res[0], res[1], res[2], res[3]};
-      store_mu_block(Mb, Ub, wave, q, rv, lr, lk);
+      for (int w = 1; w < NBT; ++w) {
+        if (w <= col) continue;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) SB(w, col)[(lk + 4 * c) * PV_DLD + lr] = X[w][c];
+      }
+      __syncthreads();
     }
-    __syncthreads();
   }
   PIV_STAMP(3);
   // ---------------- phase 3: P = M^T M, wave a computes P[a, 0..a]; A_kk <- -P (both triangles).
@@ -657,7 +718,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   if (tid == 0) { atomicAdd(&g_piv_trace[0], 1ull); atomicAdd(&g_piv_trace[6], __builtin_readcyclecounter() - piv_t0); }
 #endif
 }
-#define PIVOT_LDS_BYTES ((PV_NBLK * PV_BLK + NBT * PV_BLK) * sizeof(double))
+#define PIVOT_LDS_BYTES ((PV_NBLK * PV_BLK) * sizeof(double))
 
 
 // ------------------------------------------------- shared MFMA tile-product pieces
