@@ -1110,7 +1110,7 @@ __device__ __forceinline__ void tile_product_dma2(const double* __restrict__ A1,
 // tile (k,k) of -A^-1 after pivot step k: -P = -M^T M (what k_pivot's phase 3 computes when asked to)
 template <bool STRIP>
 __device__ __forceinline__ void form_ptile(double* __restrict__ Tkk, const double* __restrict__ M, double* __restrict__ lds,
-                                           int wave, int lane) {
+                                           int wave, int lane, bool mirror) {
   const int lr = lane & 15, lk = lane >> 4;
   v4d acc[NBT];
 #pragma unroll
@@ -1123,8 +1123,10 @@ __device__ __forceinline__ void form_ptile(double* __restrict__ Tkk, const doubl
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
   }
-  __syncthreads();
-  store_strip_transposed(acc, Tkk, (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
+  if (mirror) {
+    __syncthreads();
+    store_strip_transposed(acc, Tkk, (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
+  }
 }
 
 template <int SKIP1, bool NEG1, int SKIP2, bool NEG2, bool LATEC, bool STRIP>
@@ -1158,7 +1160,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
   double* Ab = A + (size_t)b * N * N;
   if constexpr (!G1) {
     if (sel < 0 && t0 == ntri1 + nblk - 1) {
-      form_ptile<STRIP>(Ab + TILE_OFF(k, k, nblk), Mbuf + (size_t)b * NB * NB, lds, wave, lane);
+      form_ptile<STRIP>(Ab + TILE_OFF(k, k, nblk), Mbuf + (size_t)b * NB * NB, lds, wave, lane, true);
       return;
     }
   }
@@ -1194,8 +1196,14 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
       }
-      __syncthreads();   // chunk buffers are free: per-wave transposition scratch
-      store_strip_transposed(acc, Ab + TILE_OFF(I, I, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
+      // The blocks above the diagonal of a diagonal tile are a mirror nobody reads during the sweep (k_pivot, the
+      // C reads of later updates and k_grad2_8 take the blocks on and below it): only a launch that can be the last one
+      // to touch the tile writes them (for gpsr_invert's callers, k_grad1r and the generic k_grad2); the restricted
+      // first half of a pivot pair and k_update2 are always followed by a single step and skip the mirror.
+      if (G1 || sel < 0) {
+        __syncthreads();   // chunk buffers are free: per-wave transposition scratch
+        store_strip_transposed(acc, Ab + TILE_OFF(I, I, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
+      }
       if (G1) grad1_partials(acc, true, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
     } else {
       tile_product_latec<STRIP>(Aop, NB, Bop, NB, lds, acc, Ct, (size_t)NB, wave, lane);
@@ -1241,6 +1249,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
 //   (c) tile (k1,k1) (= -P1 from pivot k1):  A_k1k1 -= W2_k1 W2_k1^T;  with ptile (c'): A_k1k1 = -M1^T M1 - W2_k1 W2_k1^T
 //   (d) I != k2:                             A_Ik2  = W2_I M2                  (pivot column of step k2)
 //   (e) tile (k2,k2), with ptile:            A_k2k2 = -M2^T M2
+// Diagonal tiles: blocks on and below the diagonal only (no mirror: a single step always follows, see k_update).
 // grid.x = (ntri(nblk-2) + (nblk-2) + 1 + (nblk-1) + ptile) * B.
 template <bool STRIP>
 __global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
@@ -1282,8 +1291,6 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
 #pragma unroll
         for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
       }
-      __syncthreads();
-      store_strip_transposed(acc, Ab + TILE_OFF(I, I, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
     } else {
 #ifdef GPSR_UPD_TRACE
       const unsigned long long trc_t1 = TRC_CLK();
@@ -1346,10 +1353,8 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
     }
-    __syncthreads();
-    store_strip_transposed(acc, Ab + TILE_OFF(k1, k1, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
   } else if (ptile && t0 == per - 1) {                // (e)
-    form_ptile<STRIP>(Ab + TILE_OFF(k2, k2, nblk), M2buf + (size_t)b * NB * NB, lds, wave, lane);
+    form_ptile<STRIP>(Ab + TILE_OFF(k2, k2, nblk), M2buf + (size_t)b * NB * NB, lds, wave, lane, false);
   } else {                                            // (d)
     int I = t0 - (ntri2 + nb2 + 1); if (I >= k2) ++I;
 #pragma unroll
