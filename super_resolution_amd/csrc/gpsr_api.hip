@@ -198,10 +198,11 @@ static int launch_pivot(double* A, int B, int N, int k, double* U, double* M, do
   return 0;
 }
 // Small batches run the tile products in strip mode (gpsr_kernels.hpp): one wave per workgroup, seven workgroups per tile.
-// Used while the launch in strip form still fits the GPU at once (two such workgroups per CU): measured on n = 784, B = 1, 2
-// every launch is 10-35 % shorter, at B = 4 the panel and the restricted update still are, the full updates no longer.
+// Used while the launch in strip form still fits the GPU at once (48 KB of LDS each: three such workgroups per CU, 768
+// slots): measured on n = 784, B = 1, 2 every launch is 10-35 % shorter, at B = 4 the panel and the restricted update
+// still are, the full updates (756 single-wave workgroups then) no longer.
 static const bool g_strip = getenv("GPSR_NO_STRIP") == nullptr;   // debugging switch
-static inline bool strip_mode(int tiles) { return g_strip && tiles * NBT <= 512; }
+static inline bool strip_mode(int tiles) { return g_strip && tiles * NBT <= 700; }
 
 static int launch_panel(const double* A, int B, int N, int k, const double* U, double* Wo, hipStream_t st) {
   const int nblk = N / NB, tp = (nblk - 1) * B;

@@ -1147,7 +1147,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
              const double* __restrict__ y, const float* __restrict__ raw, int n, double* __restrict__ part,
              int sel, int ptile) {   // ptile (sel < 0, never with G1): one more tile per GP, (k,k) = -M^T M
   static_assert(!(G1 && STRIP), "the alpha epilogue reduces across the waves of a workgroup");
-  __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
+  __shared__ __attribute__((aligned(16))) double lds[STRIP ? S_STAGES * SCH : 4 * DMA_CHUNK];   // strip form: 48 KB, three workgroups per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int vv = xcd_remap(blockIdx.x, total);
   const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1166,7 +1166,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
   }
   const int lr = lane & 15, lk = lane >> 4;
   v4d acc[NBT];
-  __shared__ double rv[2 * NB];   // G1 only: r = y - c of the tile's row and column blocks
+  __shared__ double rv[G1 ? 2 * NB : 1];   // G1 only: r = y - c of the tile's row and column blocks
   int I, J;
   bool trailing;
   if (sel < 0) {
@@ -1256,7 +1256,7 @@ __global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
 k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restrict__ Wo1,
           const double* __restrict__ Wo2, const double* __restrict__ M1buf, const double* __restrict__ M2buf,
           int total, int ptile) {   // ptile: the pivots left tiles (k1,k1), (k2,k2) to this launch (roles (c'), (e))
-  __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
+  __shared__ __attribute__((aligned(16))) double lds[STRIP ? S_STAGES * SCH : 4 * DMA_CHUNK];   // strip form: 48 KB, three workgroups per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int vv = xcd_remap(blockIdx.x, total);
   const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1416,7 +1416,7 @@ template <bool STRIP>
 __global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
 k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Ubuf,
          double* __restrict__ Wo, int total) {
-  __shared__ __attribute__((aligned(16))) double lds[4 * DMA_CHUNK];
+  __shared__ __attribute__((aligned(16))) double lds[STRIP ? S_STAGES * SCH : 4 * DMA_CHUNK];   // strip form: 48 KB, three workgroups per CU
   const int tid = threadIdx.x, lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
   const int vv = xcd_remap(blockIdx.x, total);
