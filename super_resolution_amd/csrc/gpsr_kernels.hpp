@@ -353,9 +353,9 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
 
 // ------------------------------------------------------------ pivot block
 // One workgroup (7 waves) per GP factors the NBxNB pivot block S = A_kk in LDS:
-//   phase 1  blocked Cholesky S = L L^T (16x16 sub-blocks; every wave factors the
-//            16x16 diagonal sub-block redundantly in registers, so inv(L16)^T is at
-//            hand as the B operand of the sub-panel product with no LDS hand-off)
+//   phase 1  blocked Cholesky S = L L^T (16x16 sub-blocks; the wave that owns diagonal sub-block q+1 updates it
+//            with panel column q and factors + inverts it in registers at once (look-ahead, chol16_inv), publishing
+//            inv(L16) in LDS for the next sub-panel product, while the others finish the trailing update of step q)
 //   phase 2  M = L^-1 by block forward substitution, one block column per wave, in registers
 //   phase 3  P = M^T M = U U^T  ->  A_kk <- -P   (the pivot block of -A^-1; with_p, else left to the update launch)
 //   U and M go to global for the panel / update kernels block by block, as each becomes final.
