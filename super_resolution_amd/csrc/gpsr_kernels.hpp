@@ -916,7 +916,12 @@ __device__ __forceinline__ void strip_mfma(const double* __restrict__ buf, v4d a
   }
 }
 
-template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
+// Wait until at most N_ of this wave's vector-memory operations are outstanding AND all of its LDS reads have returned:
+// the DMA issued next overwrites the stage whose operands the previous iteration read, and an LDS read that has been
+// issued but is still queued behind other workgroups' LDS traffic can be overtaken by DMA data that hits in L2 (seen
+// as garbage operands -> non-positive pivots once a second process shared the GPU; the workgroup form is safe because
+// __syncthreads() drains lgkmcnt before its barrier).
+template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(N_) : "memory"); }
 
 // acc (+)= (+-)A1 B1 [+ (+-)A2 B2]: NPH phases of 7 chunks, one continuous stream.  LATEC: acc starts at zero and the
 // strip of C (Ct, ldc) is loaded behind chunk 0's DMA and added after chunk 0's products (as tile_product_dma_latec).

@@ -78,3 +78,43 @@ def test_two_ranks_on_one_gpu_sharded_equals_unsharded(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "shard-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+
+
+CHILD3 = r"""
+import os, sys
+sys.path.insert(0, %r)
+sys.path.insert(0, os.path.join(%r, "tests"))
+import numpy as np, torch, torch.distributed as dist
+from super_resolution_amd import dist as gdist, kernels as K, ops
+from super_resolution_amd.gprsr import GPRSR, ColorSpace
+from test_gpu_kernels import natural_image
+rank, world, local = gdist.init_from_env()
+torch.cuda.set_device(local)
+dev = torch.device("cuda", local)
+imgs = [np.rint(natural_image(58 + (s * 5) %% 7, 57 + (s * 3) %% 8, s) * 255).astype(np.uint8) for s in range(1, 15)]   # 14 chains: 7 per rank
+dimgs = [ops.u8_to_unit(torch.as_tensor(im).to(dev)) for im in imgs]
+dist.barrier()
+sharded = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start="chain_per_image", shard=(rank, world)).apply_for_channel_device(dimgs)
+if rank == 0:
+    whole = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start="chain_per_image").apply_for_channel_device(dimgs)
+    assert all(torch.equal(a, b) for a, b in zip(sharded, whole)), "sharded != unsharded"
+    sys.stdout.write("chain-shard-ok\n")
+dist.barrier()
+dist.destroy_process_group()
+"""
+
+
+@pytest.mark.gpu
+def test_two_ranks_on_one_gpu_chained_mode_equals_one_rank(tmp_path):
+    """Chained warm start, whole chains dealt to two ranks that share the one GPU: both processes run small-batch
+    (strip-form) launches of n = 784 at the same time on the same CUs.  This is the configuration in which the strip
+    form's missing wait on its own LDS reads showed (garbage operands, thousands of flagged GPs) while every
+    single-process test passed; bit-identical to one rank."""
+    script = tmp_path / "child3.py"
+    script.write_text(CHILD3 % (ROOT, ROOT))
+    env = dict(os.environ)
+    env.update(GPSR_LOCAL_DEVICE="0", GPSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", "29633", str(script)],
+                       capture_output=True, text=True, timeout=600, env=env)
+    assert r.returncode == 0 and "chain-shard-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

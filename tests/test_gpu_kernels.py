@@ -237,7 +237,7 @@ def test_fit_constant_patch_rbf():
         assert (pred - 0.5).abs().max().item() < 1e-6
 
 
-@pytest.mark.parametrize("n,small", [(784, 1), (784, 4), (324, 3), (1120, 2), (200, 4)])
+@pytest.mark.parametrize("n,small", [(784, 1), (784, 4), (324, 3), (1120, 2), (200, 4), (784, 10), (784, 14), (324, 30)])
 def test_small_batch_strip_mode_bit_identical(n, small):
     """Small batches run the tile products one wave per workgroup, seven workgroups per tile (strip mode), and leave
     tile (k,k) = -M^T M of a pivot step to the update launch: the arithmetic and its order are those of the large-batch
@@ -245,7 +245,7 @@ def test_small_batch_strip_mode_bit_identical(n, small):
     from super_resolution_amd import ops
     # large enough that the big batch takes the other route everywhere: workgroup-form tile products, and tile (k,k) of
     # each pivot step formed by k_pivot itself instead of by the update launch (update_forms_ptile in gpsr_api.hip)
-    B = {784: 24, 324: 96, 1120: 12, 200: 180}[n]
+    B = {784: 24, 324: 96, 1120: 12, 200: 180}[n]   # (small = 10, 14, 30: panel / restricted update still in strip form, three workgroups per CU)
     rng = np.random.default_rng(n + small)
     X = to_dev(rng.random((B, n, 8)))
     y = to_dev(rng.random((B, n)))
@@ -267,6 +267,41 @@ def test_small_batch_strip_mode_bit_identical(n, small):
     assert torch.equal(ld_s, ld_b[:small])
     for b in range(small):   # the lower block triangle is the result; the rest is scratch
         assert np.array_equal(_lower_blocks_to_full(As[b].cpu().numpy()), _lower_blocks_to_full(Ab[b].cpu().numpy()))
+
+
+def test_small_batch_under_concurrent_load_bit_identical():
+    """Four small-batch (strip-form) fits on four streams at once, each bit-identical to the same fit run alone.  The
+    strip form has no barrier: what keeps a DMA from overwriting an LDS stage that is still being read is the s_waitcnt
+    on the wave's own LDS reads before the stage is reused.  (The failure that wait fixed needed two PROCESSES sharing
+    the GPU -- tests/test_gpu_dist.py::test_two_ranks_on_one_gpu_chained_mode_equals_one_rank reproduces it; this
+    in-process version passes either way and is kept as the cheaper multi-stream check.)"""
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(11)
+    n, S = 784, 4
+    Xs_ = [to_dev(rng.random((2 + (k % 2), n, 8))) for k in range(S)]
+    ys_ = [to_dev(rng.random((x.shape[0], n))) for x in Xs_]
+    raw0 = [ops.init_hypers(y, ops.MATERN52) for y in ys_]
+    solo = []
+    for k in range(S):
+        raw = raw0[k].clone()
+        alpha, flags, loss = ops.fit(Xs_[k], ys_[k], ops.MATERN52, raw, iters=6, want_loss=True)
+        torch.cuda.synchronize()
+        assert int(flags.sum()) == 0
+        solo.append((alpha, raw, loss))
+    streams = [torch.cuda.Stream() for _ in range(S)]
+    for rep in range(3):
+        got = []
+        torch.cuda.synchronize()
+        for k in range(S):
+            with torch.cuda.stream(streams[k]):
+                raw = raw0[k].clone()
+                alpha, flags, loss = ops.fit(Xs_[k], ys_[k], ops.MATERN52, raw, iters=6, want_loss=True)
+                got.append((alpha, raw, loss, flags))
+        torch.cuda.synchronize()
+        for k in range(S):
+            assert int(got[k][3].sum()) == 0
+            for u, v in zip(got[k][:3], solo[k]):
+                assert torch.equal(u, v)
 
 
 def test_fit_dual_stream_bit_identical():
