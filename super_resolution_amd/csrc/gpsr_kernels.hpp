@@ -356,7 +356,8 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
 //   phase 1  blocked Cholesky S = L L^T (16x16 sub-blocks; the wave that owns diagonal sub-block q+1 updates it
 //            with panel column q and factors + inverts it in registers at once (look-ahead, chol16_inv), publishing
 //            inv(L16) in LDS for the next sub-panel product, while the others finish the trailing update of step q)
-//   phase 2  M = L^-1 by block forward substitution, one block column per wave, in registers
+//   phase 2  M = L^-1 by block forward substitution down the columns, row q computed DURING step q of phase 1 by the
+//            waves that have run out of factorisation work (in place of L); only the last row is left afterwards
 //   phase 3  P = M^T M = U U^T  ->  A_kk <- -P   (the pivot block of -A^-1; with_p, else left to the update launch)
 //   U and M go to global for the panel / update kernels block by block, as each becomes final.
 // Everything outside the 16x16 register kernels is f64 MFMA.  Cholesky form on both
@@ -457,7 +458,7 @@ __device__ __forceinline__ void chol16_inv(double a[4], double m[4], int lane, d
 }
 
 // Block-packed LDS image of the pivot block: the 28 lower 16x16 blocks, each [16][17];
-// (i,j), i >= j, at block index i(i+1)/2 + j.  60.9 KB -> two workgroups per CU (the 16x16 register factorisations are a serial,
+// (i,j), i >= j, at block index i(i+1)/2 + j.  60.9 KB + 15.2 KB of per-wave parking blocks = 76 KB -> two workgroups per CU (the 16x16 register factorisations are a serial,
 // latency-bound chain: a second resident workgroup fills the bubbles).
 #define PV_BLK (16 * PV_DLD)
 #define PV_NBLK (NBT * (NBT + 1) / 2)
@@ -478,6 +479,43 @@ __device__ unsigned long long g_piv_trace2[8];
 #else
 #define PIV_STAMP(i)
 #endif
+
+// Row block r of column block c of M = L^-1 (forward substitution down the column, c < r):
+//   X[r] = -inv(L16_r) * sum_{t=c..r-1} L[r,t] X[t],   X[c] = inv(L16_c),
+// from the LDS image S: L[r,t] at SB(r,t) (t < r), inv(L16_r) at SB(r,r), the finished X[t] of this column at SB(t,c)
+// (in place of L[t,c]).  The sum comes out in accumulator layout (reg cc of lane (lr,lk) = [lk+4cc][lr]), which IS the
+// MFMA B-operand layout once the k index is read as lk+4cc instead of 4ks+lk; the A operands are indexed the same way:
+// no transposition between the two products.
+#define SB_(S, i, j) ((S) + (((i) * ((i) + 1)) / 2 + (j)) * (16 * PV_DLD))
+__device__ __forceinline__ v4d minv_col_step(const double* __restrict__ S, int r, int c, int lr, int lk) {
+  v4d sum = (v4d){0.0, 0.0, 0.0, 0.0};
+  for (int t = c; t < r; ++t) {
+    const double* Lrt = SB_(S, r, t);
+    const double* Xtc = SB_(S, t, c);
+#pragma unroll
+    for (int cc = 0; cc < 4; ++cc)
+      sum = __builtin_amdgcn_mfma_f64_16x16x4f64(Lrt[lr * PV_DLD + lk + 4 * cc], Xtc[(lk + 4 * cc) * PV_DLD + lr], sum, 0, 0, 0);
+  }
+  const double* Mrr = SB_(S, r, r);
+  v4d xr = (v4d){0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+  for (int cc = 0; cc < 4; ++cc)
+    xr = __builtin_amdgcn_mfma_f64_16x16x4f64(-Mrr[lr * PV_DLD + lk + 4 * cc], sum[cc], xr, 0, 0, 0);
+  return xr;
+}
+
+// Which column block of row q of M a wave computes during step q of the factorisation (-1: none).  Row q has q blocks
+// (columns 0..q-1, block (q,c) costs q-c+1 products), waves 0..q are out of factorisation work, wave q+1 runs the
+// serial 16x16 factorisation.  Waves w and w+4 share a SIMD, and a worker on the factorising wave's SIMD costs that
+// wave ~1000 cycles per step (measured), so the blocks are dealt to idle waves on the OTHER SIMDs, longest column to
+// the least loaded SIMD; q = 6 is the row that is left after the last step (everybody idle).  The blocks live in LDS,
+// so the owner of a column may change from step to step (a barrier lies between a block's write and its next read).
+__device__ __forceinline__ int pv_col_of(int q, int wave) {
+  // nibble `wave` of entry q = column + 1
+  const unsigned tab = q == 1 ? 0x0000001u : q == 2 ? 0x0000021u : q == 3 ? 0x0003210u : q == 4 ? 0x0043201u
+                     : q == 5 ? 0x0451032u : q == 6 ? 0x0561432u : 0u;
+  return (int)((tab >> (4 * wave)) & 15u) - 1;
+}
 
 // 16x16 block (bi,bj) of M = L^-1 from the accumulator layout (v[c] = block[lk+4c][lr]) to global: M[bi][bj] and
 // U[bj][bi] = its transpose.  Issued as soon as a block is final, so the stores drain behind the remaining steps
@@ -528,6 +566,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   int bad = 0;
   double* Ub = Ubuf + (size_t)b * NB * NB;
   double* Mb = Mbuf + (size_t)b * NB * NB;
+  double* stg = sm + PV_NBLK * PV_BLK + wave * PV_BLK;   // per-wave parking block
   // ---------------- phase 1: blocked Cholesky; afterwards SB(q,q) = inv(L16_q), SB(w,q) = L[w,q]
   // The 16x16 factor+inverse is a serial register kernel: ONE wave (the owner of the diagonal
   // block) runs it and publishes inv(L16_q) in place.
@@ -601,11 +640,27 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
         }
       }
     }
+    // M = L^-1 rides along: waves 0..q have no part in step q of the factorisation (their rows are done), row q of L and
+    // inv(L16_q) are final, so they compute the blocks (q, c), c < q, of M now (minv_col_step), send them to global
+    // (M and U = M^T), park them in LDS and, once everybody is done reading L[q,.] (the barrier), put them in place of
+    // L[q,c].  After the last step only row 6 is left.  Which wave takes which column: pv_col_of.
+    const int colq = pv_col_of(q, wave);
+    if (colq >= 0) {
+      const v4d xq = minv_col_step(S, q, colq, lr, lk);
+      const double xv[4] = {xq[0], xq[1], xq[2], xq[3]};
+      store_mu_block(Mb, Ub, q, colq, xv, lr, lk);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) stg[(lk + 4 * c) * PV_DLD + lr] = xq[c];
+    }
 #ifdef GPSR_PIV_TRACE
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
     p2e = PIV2_T();
 #endif
     __syncthreads();
+    if (colq >= 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) SB(q, colq)[(lk + 4 * c) * PV_DLD + lr] = stg[(lk + 4 * c) * PV_DLD + lr];
+    }
 #ifdef GPSR_PIV_TRACE
     {
       const unsigned long long p2f = PIV2_T();
@@ -628,55 +683,21 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
       for (int w = 0; w < NBT; ++w) { ld += ldsum[w]; bad |= badsum[w]; }
     }
   }
-  // ---------------- phase 2: M = L^-1, one block COLUMN per wave, no barrier: column q of M solves L X = E_q by forward
-  // substitution down the rows,
-  //   X[q] = inv(L16_q),   X[w] = -inv(L16_w) * sum_{t=q..w-1} L[w,t] X[t],   w = q+1 .. 6,
-  // and needs nothing from the other columns.  X stays in registers in accumulator layout (reg c of lane (lr,lk) =
-  // X[lk+4c][lr]), which IS the MFMA B-operand layout once the k index is read as lk+4c instead of 4ks+lk -- the A
-  // operand (L[w,t] resp. inv(L16_w), from LDS) is simply indexed the same way -- so there is no transposition and no
-  // LDS write; L stays intact for the other waves, and every finished block goes straight to global (M and U = M^T).
-  // Column q costs (7-q)(8-q)/2 - 1 block products: 27, 20, 14, 9, 5, 2, 0.  Waves w and w+4 share a SIMD, so the
-  // columns are dealt 1,2,3,0 | 6,5,4: column 0 has a SIMD to itself, the others pair up to 20 / 16 / 14.
-  // (The right-to-left in-place form this replaces took two barriers and an LDS transposition per block column:
-  // 18.1 k of the workgroup's 75.6 k cycles, for 6.9 k cycles of MFMA time on its busiest wave.)
+  // ---------------- phase 2 (what is left of it): the last row of M = L^-1; rows 1..5 were computed by the idle waves
+  // during the factorisation.  Wave c < 6 owns column c; the last row costs it 7 - c block products.
   {
-    const int col = wave < 4 ? (wave + 1) & 3 : 10 - wave;
-    v4d X[NBT];
-#pragma unroll
-    for (int t = 0; t < NBT; ++t) {
-      if (t == col) {
-#pragma unroll
-        for (int c = 0; c < 4; ++c) X[t][c] = SB(t, t)[(lk + 4 * c) * PV_DLD + lr];
-      } else X[t] = (v4d){0.0, 0.0, 0.0, 0.0};
+    v4d x6;
+    const int col6 = pv_col_of(NBT - 1, wave);
+    if (col6 >= 0) {
+      x6 = minv_col_step(S, NBT - 1, col6, lr, lk);
+      const double xv[4] = {x6[0], x6[1], x6[2], x6[3]};
+      store_mu_block(Mb, Ub, NBT - 1, col6, xv, lr, lk);
     }
-#pragma unroll
-    for (int w = 1; w < NBT; ++w) {
-      if (w <= col) continue;
-      v4d sum = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int t = 0; t < w; ++t) {
-        if (t < col) continue;
-        const double* Lwt = SB(w, t);
-#pragma unroll
-        for (int c = 0; c < 4; ++c)
-          sum = __builtin_amdgcn_mfma_f64_16x16x4f64(Lwt[lr * PV_DLD + lk + 4 * c], X[t][c], sum, 0, 0, 0);
-      }
-      const double* Mww = SB(w, w);
-      v4d xw = (v4d){0.0, 0.0, 0.0, 0.0};
-#pragma unroll
-      for (int c = 0; c < 4; ++c)
-        xw = __builtin_amdgcn_mfma_f64_16x16x4f64(-Mww[lr * PV_DLD + lk + 4 * c], sum[c], xw, 0, 0, 0);
-      X[w] = xw;
-      const double xv[4] = {xw[0], xw[1], xw[2], xw[3]};
-      store_mu_block(Mb, Ub, w, col, xv, lr, lk);
-    }
-    if (with_p) {   // phase 3 reads M from LDS: in place of L, once every wave is done reading L
+    if (with_p) {   // phase 3 reads M from LDS
       __syncthreads();
+      if (col6 >= 0) {
 #pragma unroll
-      for (int w = 1; w < NBT; ++w) {
-        if (w <= col) continue;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) SB(w, col)[(lk + 4 * c) * PV_DLD + lr] = X[w][c];
+        for (int c = 0; c < 4; ++c) SB(NBT - 1, col6)[(lk + 4 * c) * PV_DLD + lr] = x6[c];
       }
       __syncthreads();
     }
@@ -718,7 +739,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   if (tid == 0) { atomicAdd(&g_piv_trace[0], 1ull); atomicAdd(&g_piv_trace[6], __builtin_readcyclecounter() - piv_t0); }
 #endif
 }
-#define PIVOT_LDS_BYTES ((PV_NBLK * PV_BLK) * sizeof(double))
+#define PIVOT_LDS_BYTES ((PV_NBLK * PV_BLK + NBT * PV_BLK) * sizeof(double))
 
 
 // ------------------------------------------------- shared MFMA tile-product pieces
