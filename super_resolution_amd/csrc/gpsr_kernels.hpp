@@ -588,18 +588,21 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
     const bool crit = wave == q + 1;
     unsigned long long p2a = PIV2_T(), p2b = 0, p2c = 0, p2d = 0, p2e = 0;
 #endif
+    double an[4] = {0.0, 0.0, 0.0, 0.0};
     if (wave > q) {
-      // L_wq = S[w,q] * inv(L16)^T : B operand element (k, col) = inv(L16)[col][k]
+      // L_wq = S[w,q] * inv(L16)^T, computed TRANSPOSED (A = inv(L16), B = S[w,q]: same products, same order): the
+      // accumulator then holds L_wq[lr][lk+4c], which is both the [row][k] image the other waves read from LDS and this
+      // wave's own A operand of the trailing update -- it stays in registers, no LDS read-back after the barrier
       const double* Mqq = SB(q, q);
       double* Swq = SB(wave, q);
       v4d cw = (v4d){0.0, 0.0, 0.0, 0.0};
 #pragma unroll
       for (int ks = 0; ks < 4; ++ks)
-        cw = __builtin_amdgcn_mfma_f64_16x16x4f64(Swq[lr * PV_DLD + lk + 4 * ks], Mqq[lr * PV_DLD + lk + 4 * ks], cw,
+        cw = __builtin_amdgcn_mfma_f64_16x16x4f64(Mqq[lr * PV_DLD + lk + 4 * ks], Swq[lr * PV_DLD + lk + 4 * ks], cw,
                                                   0, 0, 0);
       __builtin_amdgcn_wave_barrier();
 #pragma unroll
-      for (int c = 0; c < 4; ++c) Swq[(lk + 4 * c) * PV_DLD + lr] = cw[c];
+      for (int c = 0; c < 4; ++c) { Swq[lr * PV_DLD + lk + 4 * c] = cw[c]; an[c] = -cw[c]; }
     }
 #ifdef GPSR_PIV_TRACE
     p2b = PIV2_T();
@@ -609,10 +612,6 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
     p2c = PIV2_T();
 #endif
     if (wave > q) {
-      const double* Swq = SB(wave, q);
-      double an[4];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) an[ks] = -Swq[lr * PV_DLD + lk + 4 * ks];
       for (int j = q + 1; j <= wave; ++j) {
         double* Swj = SB(wave, j);
         const double* Sjq = SB(j, q);
