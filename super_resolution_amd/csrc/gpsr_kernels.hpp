@@ -915,7 +915,7 @@ __device__ __forceinline__ void strip_dma(const double* __restrict__ Aop, int ld
   }
 }
 
-template <int SKIP, bool NEG_A, bool ROWMAJOR_A>
+template <int SKIP, bool NEG_A, bool ROWMAJOR_A, bool SWAP = false>   // SWAP: operands exchanged, acc[t] holds the block TRANSPOSED
 __device__ __forceinline__ void strip_mfma(const double* __restrict__ buf, v4d acc[NBT], int strip, int lane, int ch) {
   const int lr = lane & 15, lk = lane >> 4;
   const double* As = buf + KC * NB;
@@ -931,7 +931,8 @@ __device__ __forceinline__ void strip_mfma(const double* __restrict__ buf, v4d a
       if (SKIP == SKIP_UPPER && t < ch) continue;
       if ((SKIP == SKIP_DIAG || SKIP == SKIP_PTP) && t > strip) continue;
       const double bv = buf[kk * NB + 16 * t + lr];
-      acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+      acc[t] = SWAP ? __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc[t], 0, 0, 0)
+                    : __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
     }
   }
 }
@@ -947,7 +948,7 @@ template <int N_> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s
 // strip of C (Ct, ldc) is loaded behind chunk 0's DMA and added after chunk 0's products (as tile_product_dma_latec).
 // Every strip_dma is 16 LDS-DMA instructions, the 28 loads of C sit between chunk 0's and chunk 1's: waiting for
 // chunk g leaves exactly the instructions issued after it outstanding.
-template <int SKIP1, bool NEG1, int SKIP2, bool NEG2, bool LATEC, int NPH, bool ROWMAJOR_A1>
+template <int SKIP1, bool NEG1, int SKIP2, bool NEG2, bool LATEC, int NPH, bool ROWMAJOR_A1, bool SWAP = false>
 __device__ __forceinline__ void strip_product(const double* __restrict__ A1, int lda1, const double* __restrict__ B1, int ldb1,
                                               const double* __restrict__ A2, int lda2, const double* __restrict__ B2, int ldb2,
                                               double* __restrict__ lds, v4d acc[NBT], const double* __restrict__ Ct, size_t ldc,
@@ -975,8 +976,8 @@ __device__ __forceinline__ void strip_product(const double* __restrict__ A1, int
       if (g + 2 < NC) strip_dma<ROWMAJOR_A1>(A1, lda1, B1, ldb1, g + 2, nxt, strip, lane);
       else strip_dma<false>(A2, lda2, B2, ldb2, g + 2 - NC, nxt, strip, lane);
     }
-    if (g < NC) strip_mfma<SKIP1, NEG1, ROWMAJOR_A1>(cur, acc, strip, lane, g);
-    else strip_mfma<SKIP2, NEG2, false>(cur, acc, strip, lane, g - NC);
+    if (g < NC) strip_mfma<SKIP1, NEG1, ROWMAJOR_A1, SWAP>(cur, acc, strip, lane, g);
+    else strip_mfma<SKIP2, NEG2, false, SWAP>(cur, acc, strip, lane, g - NC);
     if (LATEC && g == 0) {
 #pragma unroll
       for (int t = 0; t < NBT; ++t) acc[t] += c0[t];
@@ -1458,8 +1459,8 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
 #pragma unroll
   for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
   if constexpr (STRIP) {
-    if (below) strip_product<SKIP_UPPER, false, SKIP_NONE, false, false, 1, true>(Tsrc, NB, U, NB, nullptr, 0, nullptr, 0, lds, acc, nullptr, 0, wave, lane);
-    else strip_product<SKIP_UPPER, false, SKIP_NONE, false, false, 1, false>(Tsrc, NB, U, NB, nullptr, 0, nullptr, 0, lds, acc, nullptr, 0, wave, lane);
+    if (below) strip_product<SKIP_UPPER, false, SKIP_NONE, false, false, 1, true, true>(Tsrc, NB, U, NB, nullptr, 0, nullptr, 0, lds, acc, nullptr, 0, wave, lane);
+    else strip_product<SKIP_UPPER, false, SKIP_NONE, false, false, 1, false, true>(Tsrc, NB, U, NB, nullptr, 0, nullptr, 0, lds, acc, nullptr, 0, wave, lane);
   } else {
   dma_chunk_panel(Tsrc, (size_t)NB, below, U, 0, lds, lds + DMA_CHUNK, wave, lane);
   const int r = 16 * wave + lr, rsw = (r >> 1) & 7;
@@ -1479,14 +1480,20 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
       for (int t = 0; t < NBT; ++t) {
         if (t < ch) continue;
         const double bv = Bs[kk * NB + 16 * t + lr];
-        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(av, bv, acc[t], 0, 0, 0);
+        acc[t] = __builtin_amdgcn_mfma_f64_16x16x4f64(bv, av, acc[t], 0, 0, 0);
       }
     }
   }
   }
-  __syncthreads();
-  // acc[t][rr] = W[r = 16*wave + lk + 4rr][k' = 16t + lr]  ->  Wo[k'][i0 + r]
-  store_strip_transposed(acc, Wo + (size_t)b * NB * N + (size_t)i * (NB * NB), (size_t)NB, lds, wave, lane, 1.0, nullptr);
+  // The product is computed TRANSPOSED (U as the A operand, T as the B operand: same LDS reads, same products in the
+  // same order), so the accumulators hold the k-major panel image itself,
+  //   acc[t][rr] = W[r = 16*wave + lr][k' = 16t + lk + 4rr]  ->  Wo[k'][i0 + r],
+  // and go out as 128-byte row segments with no transposition through LDS.
+  double* Wt = Wo + (size_t)b * NB * N + (size_t)i * (NB * NB) + 16 * wave + lr;
+#pragma unroll
+  for (int t = 0; t < NBT; ++t)
+#pragma unroll
+    for (int rr = 0; rr < 4; ++rr) Wt[(size_t)(16 * t + lk + 4 * rr) * NB] = acc[t][rr];
 }
 
 // ------------------------------------------------------------------ grad1
