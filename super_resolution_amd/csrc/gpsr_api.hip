@@ -357,7 +357,7 @@ static int launch_op(const Op& op, const Batch& h, const FitShape& c) {
     case OP_BUILD:
       return launch_build(h.X, B, c.n, N, c.d, c.kid, h.raw, w.A, w.logdet, st, 0);   // diagonal tiles: lower sub-blocks only
     case OP_PIVOT:
-      return launch_pivot(w.A, B, N, op.k, w.inv.U[op.set], w.inv.M[op.set], w.logdet, h.flags, update_forms_ptile(op.arg, B, nblk) ? 0 : 1, st);
+      return launch_pivot(w.A, B, N, op.k, w.inv.U[op.set], w.inv.M[op.set], w.logdet, h.flags, update_forms_ptile(op.arg, B, nblk) ? 0 : (op.k == nblk - 1 ? 2 : 1), st);
     case OP_PANEL:
       return launch_panel(w.A, B, N, op.k, w.inv.U[op.set], Wo, st);
     case OP_UPD_SEL: {

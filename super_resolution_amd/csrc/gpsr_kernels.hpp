@@ -702,7 +702,8 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
     }
   }
   PIV_STAMP(3);
-  // ---------------- phase 3: P = M^T M, wave a computes P[a, 0..a]; A_kk <- -P (both triangles).
+  // ---------------- phase 3: P = M^T M, wave a computes P[a, 0..a]; A_kk <- -P (with_p > 1: both triangles -- only the
+  // last pivot of a sweep needs the mirror, every other pivot tile is updated and mirrored again by a later step).
   // Only when nothing follows that can do it (with_p: single-block matrices, the step before the alpha epilogue):
   // otherwise the update launch of the same step forms -M^T M as one more tile product (form_ptile: same products in
   // the same order, bit-identical), next to its other tiles instead of on this latency-bound workgroup's path.
@@ -722,7 +723,7 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         Akk[(size_t)(16 * a + lk + 4 * c) * NB + 16 * bb + lr] = -acc[c];
-        if (bb != a) Akk[(size_t)(16 * bb + lr) * NB + 16 * a + lk + 4 * c] = -acc[c];
+        if (bb != a && with_p > 1) Akk[(size_t)(16 * bb + lr) * NB + 16 * a + lk + 4 * c] = -acc[c];
       }
     }
   }
