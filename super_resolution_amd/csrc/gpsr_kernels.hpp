@@ -47,6 +47,22 @@ __device__ __forceinline__ Hyp load_hyp(const float* __restrict__ raw) {
   return h;
 }
 
+// The same, computed by ONE wave of the workgroup and handed to the others through LDS (hs: 6 doubles; the caller's
+// next __syncthreads() publishes it, load_hyp_shared_get reads it after that barrier).  The constraint transforms are
+// ~450 instructions (three softplus: expf, log1pf; two divisions) against ~2200 in the pair loop of a k_build8 /
+// k_grad2_8 thread: done by every wave they were a fifth of those launches.
+__device__ __forceinline__ void load_hyp_shared_put(const float* __restrict__ raw, double* __restrict__ hs, int tid) {
+  if (tid < 64) {
+    const Hyp h = load_hyp(raw);
+    if (tid == 0) { hs[0] = h.noise; hs[1] = h.mean; hs[2] = h.os; hs[3] = h.ls; hs[4] = h.il; hs[5] = h.il2; }
+  }
+}
+__device__ __forceinline__ Hyp load_hyp_shared_get(const double* __restrict__ hs) {
+  Hyp h;
+  h.noise = hs[0]; h.mean = hs[1]; h.os = hs[2]; h.ls = hs[3]; h.il = hs[4]; h.il2 = hs[5];
+  return h;
+}
+
 // ---- lean f64 sqrt / exp for the pair loops (k_build8, k_grad2_8, k_predict are bound by the f64 VALU issue
 // rate; libm's versions spend a third of their instructions on range scaling and special cases that cannot occur
 // here, and the compiler turns every Horner step on a constant into v_mov_b64 + v_fmac_f64).
@@ -332,23 +348,36 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
     const int gi = I * NB + (e >> 3);
     xi[e] = gi < n ? Xb[(size_t)I * NB * 8 + e] : 0.0;
   }
-  const Hyp h = load_hyp(raw + 4 * b);
+  __shared__ double hs[6];
+  load_hyp_shared_put(raw + 4 * b, hs, tid);
   if (t == 0 && tid == 0 && logdet) logdet[b] = 0.0;
   __syncthreads();
+  const Hyp h = load_hyp_shared_get(hs);
   double* Ab = A + (size_t)b * N * N + TILE_OFF(I, J, N / NB) + j;
+  // Rows of real points first, padding rows (identity) after; an off-diagonal tile has no diagonal element, so its
+  // loop carries neither the noise term nor any per-element test (same arithmetic per element; the tests and the
+  // select cost a fifth of the instructions of the loop).
+  const int ireal = min(iend, n - I * NB);            // rows i < ireal are real points (may be <= i0)
+  if (gj < n) {
+    if (I != J) {
 #pragma unroll 2
-  for (int i = i0; i < iend; i += istep) {
-    const int gi = I * NB + i;
-    double val;
-    if (gi < n && gj < n) {
-      const double st = pair_stat<KID>(xi + i * 8, xj, 8);
-      val = h.os * kern_val<KID>(st, h);
-      if (gi == gj) val += h.noise;
+      for (int i = i0; i < ireal; i += istep) {
+        const double st = pair_stat<KID>(xi + i * 8, xj, 8);
+        Ab[(size_t)i * NB] = h.os * kern_val<KID>(st, h);
+      }
     } else {
-      val = (gi == gj) ? 1.0 : 0.0;
+#pragma unroll 2
+      for (int i = i0; i < ireal; i += istep) {
+        const double st = pair_stat<KID>(xi + i * 8, xj, 8);
+        double val = h.os * kern_val<KID>(st, h);
+        if (i == j) val += h.noise;
+        Ab[(size_t)i * NB] = val;
+      }
     }
-    Ab[(size_t)i * NB] = val;
   }
+  int ipad = i0;                                       // first row of this thread's walk that is padding
+  if (gj < n && ireal > i0) ipad = i0 + ((ireal - i0 + istep - 1) / istep) * istep;
+  for (int i = ipad; i < iend; i += istep) Ab[(size_t)i * NB] = (I == J && i == j) ? 1.0 : 0.0;
 }
 
 // ------------------------------------------------------------ pivot block
@@ -1714,22 +1743,25 @@ k_grad2_8(const double* __restrict__ A, const double* __restrict__ X, const floa
     xi[e] = gi < n ? Xb[(size_t)I * NB * 8 + e] : 0.0;
   }
   if (tid < NB) ai[tid] = alpha[(size_t)b * N + I * NB + tid];
-  const Hyp h = load_hyp(raw + 4 * b);
+  __shared__ double hs[6];
+  load_hyp_shared_put(raw + 4 * b, hs, tid);
   __syncthreads();
+  const Hyp h = load_hyp_shared_get(hs);
   const double* Ab = A + (size_t)b * N * N + TILE_OFF(I, J, N / NB) + j;
   double s0 = 0.0, s1 = 0.0;
   if (gj < n) {
+    const int ireal = min(iend, n - I * NB);   // padding rows contribute nothing
 #pragma unroll 2
-    for (int i = i0; i < iend; i += istep) {
-      if (I * NB + i < n) {
-        const double w = wsym * (-Ab[(size_t)i * NB] - ai[i] * aj);
-        const double st = pair_stat<KID>(xi + i * 8, xj, 8);
-        double kv, dk;
-        kern_val_dl<KID>(st, h, kv, dk);
-        s0 = fma(w, kv, s0);
-        s1 = fma(w, dk, s1);
-      }
+    for (int i = i0; i < ireal; i += istep) {
+      const double w = -Ab[(size_t)i * NB] - ai[i] * aj;
+      const double st = pair_stat<KID>(xi + i * 8, xj, 8);
+      double kv, dk;
+      kern_val_dl<KID>(st, h, kv, dk);
+      s0 = fma(w, kv, s0);
+      s1 = fma(w, dk, s1);
     }
+    s0 *= wsym; s1 *= wsym;   // 1 or 2: exact, and it commutes with every rounding of the sums above (bit-identical
+                              // to scaling each weight)
   }
   const int lane = tid & 63, wave = tid >> 6;
 #pragma unroll
