@@ -1048,6 +1048,16 @@ __device__ __forceinline__ void grad1_stage_r(double* __restrict__ rv, const dou
   }
 }
 
+// x + (x of the lane's partner under a DPP row permutation): quad_perm [1,0,3,2] (0xB1), [2,3,0,1] (0x4E), row_half_mirror
+// (0x141), row_mirror (0x140) in turn sum the 16 lanes of a row into every lane -- the same pairs, hence the same bits,
+// as the xor-1/2/4/8 butterfly of __shfl_xor, without its eight ds_bpermute round trips through the LDS pipeline.
+template <int CTRL>
+__device__ __forceinline__ double dpp_add(double x) {
+  const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), CTRL, 0xF, 0xF, false);
+  const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), CTRL, 0xF, 0xF, false);
+  return x + __hiloint2double(hi, lo);
+}
+
 __device__ __forceinline__ void grad1_partials(const v4d acc[NBT], bool diag, const double* __restrict__ rv,
                                                double* __restrict__ lds, double* __restrict__ part, int wave,
                                                int lane, int tid) {
@@ -1063,11 +1073,13 @@ __device__ __forceinline__ void grad1_partials(const v4d acc[NBT], bool diag, co
 #pragma unroll
     for (int t = 0; t < NBT; ++t)
       if (!diag || t <= wave) p = fma(acc[t][rr], rJ[t], p);
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) p += __shfl_xor(p, o);
+    p = dpp_add<0xB1>(p); p = dpp_add<0x4E>(p); p = dpp_add<0x141>(p); p = dpp_add<0x140>(p);
     if (lr == 0) part[16 * wave + lk + 4 * rr] = p;
   }
-  double* cb = lds + G1_COLBUF + wave * NB;
+  // column sums: the four row groups (lk) of a wave leave their partials side by side in LDS and the final pass adds
+  // them as the xor-16 / xor-32 butterfly would, (q0 + q1) + (q2 + q3), then the waves in order: same bits, no
+  // cross-row shuffles
+  double* cb = lds + G1_COLBUF + (wave * 4 + lk) * NB;
 #pragma unroll
   for (int t = 0; t < NBT; ++t) {
     double q = 0.0;
@@ -1075,15 +1087,16 @@ __device__ __forceinline__ void grad1_partials(const v4d acc[NBT], bool diag, co
 #pragma unroll
       for (int rr = 0; rr < 4; ++rr) q = fma(acc[t][rr], rI[rr], q);
     }
-    q += __shfl_xor(q, 16);
-    q += __shfl_xor(q, 32);
-    if (lk == 0) cb[16 * t + lr] = q;
+    cb[16 * t + lr] = q;
   }
   __syncthreads();
   if (tid < NB) {
     double sacc = 0.0;
 #pragma unroll
-    for (int w = 0; w < NBT; ++w) sacc += lds[G1_COLBUF + w * NB + tid];
+    for (int w = 0; w < NBT; ++w) {
+      const double* c4 = lds + G1_COLBUF + (w * 4) * NB + tid;
+      sacc += (c4[0] + c4[NB]) + (c4[2 * NB] + c4[3 * NB]);
+    }
     part[NB + tid] = sacc;
   }
 }
