@@ -314,6 +314,24 @@ int gpsr_metrics(const uint8_t* a, const uint8_t* b, int H, int W, int crop, dou
                  void* workspace, size_t workspace_bytes, void* stream);
 
 /*
+ * AGPR training-set selection ("active sampling", agpr.py:120-137 with get_characteristic_score / get_diversity
+ * :211-222).  data: [N][D] f64 candidate rows (49 bicubic pixels + the HR centre pixel,
+ * np.unique'd, agpr.py:113-118).  Three launches: the [N][N] squared distances (:123-124), the representativeness
+ * score of every row from its K nearest neighbours (:126-128), and the greedy loop that picks n_pick rows by
+ * argmax of w_rep * representativeness + w_div * diversity (:132-137; w_rep = CHARACTERISTIC_TRADEOFF, w_div =
+ * 1 - CHARACTERISTIC_TRADEOFF as the host evaluates it).  bandwidth is agpr.py:125's value, which the host computes
+ * (it is a median of the INDICES np.where returns: 0.2 * (N - 1) / 2 for finite data).  Kept from the reference
+ * because they decide the choice: the score array is indexed by the position in the shrinking pool, sums run in
+ * numpy's order (distances bit-identical to numpy's), np.argmax's first-maximum rule.
+ *   out_idx : [n_pick] int32, indices into data in the order chosen     rep_out : [N] scores, or NULL
+ * D <= 128, K <= 64, N <= 46340.  Workspace: gpsr_active_sample_workspace_bytes(N) (N = 5000: 200 MB).
+ */
+size_t gpsr_active_sample_workspace_bytes(int N);
+int gpsr_active_sample(const double* data, int N, int D, int K, int n_pick, double bandwidth, double w_rep,
+                       double w_div, int32_t* out_idx, double* rep_out, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/*
  * Kernel timing for bench.py's roofline line: HIP-event brackets around the
  * tagged launches, on the stream they are launched on.  No counterpart in the
  * reference (its only instrumentation is time.time() per image, gprsr.py:49-72).

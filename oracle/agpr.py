@@ -8,6 +8,8 @@ Restates agpr.py of the reference:
   iterative_back_projection agpr.py:192-209
   downscale                 agpr.py:244-246 (GaussianBlur 3x3 sigma 1 + INTER_CUBIC by the MODULE-GLOBAL SRF)
   upscale                   agpr.py:148-158 (YCrCb: GP on Y, bicubic Cr/Cb)
+  active_sampling           agpr.py:120-137, 211-222 (training-set selection; numpy is the reference's own library
+                            here, so this part runs the same numpy calls on the same values: pinned by construction)
 The fit is pinned by the reference's checkpoints (tests/test_oracle.py); the
 image part goes through the unpinned OpenCV restatement (oracle/cvops.py).
 """
@@ -73,3 +75,44 @@ def upscale(bgr, srf, h, train_x, train_y, grayscale=False, global_srf=None):
     cr = cvops.resize_cubic(ycc[..., 1], dsize=(y.shape[1], y.shape[0]))
     cb = cvops.resize_cubic(ycc[..., 2], dsize=(y.shape[1], y.shape[0]))
     return cvops.ycrcb2bgr(np.stack([y, cr, cb], axis=-1))
+
+
+def active_sampling(data, K=10, n_pick=500, bandwidth_coeff=0.2, tradeoff=0.2):
+    """agpr.py:120-137 on the np.unique'd candidate rows `data` [N, D].
+
+    -> (indices of the chosen rows in the order chosen, chosen rows, representativeness scores, bandwidth).
+    The reference keeps rows, not indices; the indices are carried along here so that a device
+    implementation can be compared exactly.  Kept as the reference has them:
+      * :123  distances by broadcasting (memory O(N^2 D): small N only), numpy's summation order;
+      * :125  bandwidth = coeff * median of the INDEX arrays np.where returns (not of the distances);
+      * :126  K nearest by argsort of each row;
+      * :133  score i uses representativeness_scores[i] with i the position in the SHRINKING pool (:136 deletes
+              from the pool, the score array is never deleted from);
+      * :222  diversity = min over the chosen rows of -exp(-d / 2bw), 0 while nothing is chosen (:218).
+    """
+    data = np.asarray(data, dtype=np.float64)
+    dist = np.sum((data[:, None, :] - data[None, :, :]) ** 2, axis=-1)
+    np.fill_diagonal(dist, np.inf)
+    bandwidth = bandwidth_coeff * np.median(np.where(dist != np.inf))
+    near = np.argsort(dist, axis=1)[:, :K]
+    near_d = np.take_along_axis(dist, near, axis=-1)
+    rep = np.mean(np.exp(-near_d / (2 * bandwidth)), axis=-1)
+
+    pool = np.copy(data)
+    pool_idx = np.arange(len(data))
+    chosen, chosen_idx = [], []
+    for _ in range(n_pick):
+        scores = []
+        for i, row in enumerate(pool):
+            if len(chosen) == 0:
+                diversity = 0
+            else:
+                sel_d = np.sum((chosen - row) ** 2, axis=1)
+                diversity = np.min(-np.exp(-sel_d / (2 * bandwidth)))
+            scores.append(tradeoff * rep[i] + (1 - tradeoff) * diversity)
+        j = np.argmax(scores)
+        chosen.append(pool[j])
+        chosen_idx.append(int(pool_idx[j]))
+        pool = np.delete(pool, j, axis=0)
+        pool_idx = np.delete(pool_idx, j)
+    return np.array(chosen_idx), np.array(chosen), rep, bandwidth

@@ -14,8 +14,9 @@ What runs where:
     7x7 window, so the per-pixel GP calls collapse into ONE 49-tap filter
     (gpsr_agpr_weights + gpsr_agpr_filter) over the bicubic image;
   * back-projection (agpr.py:192-209): blur / resize / 3x3 sharpen kernels on the GPU;
-  * training-set selection (agpr.py:92-146): host numpy, as in the reference (unseeded
-    np.random, O(N^2) distances) -- out of the accelerated path.
+  * training-set selection (agpr.py:92-146): the random candidate draw and np.unique stay host numpy as
+    in the reference (unseeded np.random); the active sampling proper (agpr.py:120-137: O(N^2 D) distances,
+    K-nearest-neighbour scores, 500 greedy rounds) is gpsr_active_sample on the GPU.
 """
 import os
 from enum import Enum
@@ -188,30 +189,18 @@ class AGPRSuperResolution:
             print("Training data set in {:.2f} seconds".format(time() - t0))
 
     def _active_sampling(self, data):
-        """agpr.py:122-137, quirks included (median of *indices*, scores indexed by the
-        position in the shrinking pool, diversity = min(-exp(.)))."""
-        sq = (data * data).sum(1)
-        distances = sq[:, None] + sq[None, :] - 2.0 * data @ data.T
-        np.fill_diagonal(distances, np.inf)
-        self.bandwidth = SCALE_COEFFICIENT_BANDWIDTH * np.median(np.where(distances != np.inf))
-        nidx = np.argsort(distances, axis=1)[:, :K]
-        ndist = np.take_along_axis(distances, nidx, axis=-1)
-        self.representativeness_scores = np.mean(np.exp(-ndist / (2 * self.bandwidth)), axis=-1)
-        pool = np.copy(data)
-        chosen = []
-        div = np.zeros(len(pool))                      # running min over chosen of -exp(-d/2bw); 0 while empty
-        for _ in range(floor(ACTIVE_SAMPLING_RATIO * N)):
-            rep = self.representativeness_scores[:len(pool)]
-            score = CHARACTERISTIC_TRADEOFF * rep + (1 - CHARACTERISTIC_TRADEOFF) * div
-            j = int(np.argmax(score))
-            pick = pool[j]
-            pool = np.delete(pool, j, axis=0)
-            div = np.delete(div, j)
-            chosen.append(pick)
-            d = ((pool - pick) ** 2).sum(1)
-            cand = -np.exp(-d / (2 * self.bandwidth))
-            div = cand if len(chosen) == 1 else np.minimum(div, cand)
-        return chosen
+        """agpr.py:122-137 on the GPU (gpsr_active_sample): distances, representativeness scores and the greedy loop
+        are three launches; the reference's habits that decide the choice are kept (scores indexed by the position
+        in the shrinking pool, numpy's summation order, first maximum wins).  The bandwidth (agpr.py:125) is a
+        median of the INDEX arrays np.where returns, not of the distances: every index 0..N-1 occurs 2(N-1)
+        times in them (all distances off the diagonal are finite), so it is 0.2 * (N-1)/2 whatever the data."""
+        n = len(data)
+        self.bandwidth = SCALE_COEFFICIENT_BANDWIDTH * ((n - 1) / 2.0)
+        idx, rep = ops.active_sample(_to_dev(data), K, floor(ACTIVE_SAMPLING_RATIO * N), self.bandwidth,
+                                     CHARACTERISTIC_TRADEOFF, 1 - CHARACTERISTIC_TRADEOFF)
+        self.representativeness_scores = rep.cpu().numpy()
+        self.active_indices = idx.cpu().numpy()
+        return [data[i] for i in self.active_indices]
 
     def get_characteristic_score(self, i, datapoint) -> float:
         return (CHARACTERISTIC_TRADEOFF * self.representativeness_scores[i]

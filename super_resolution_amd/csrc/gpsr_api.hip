@@ -1020,6 +1020,48 @@ extern "C" int gpsr_metrics(const uint8_t* a, const uint8_t* b, int H, int W, in
   return 0;
 }
 
+// ---------------------------------------------------------------- AGPR training-set selection
+static void as_carve(void* workspace, int N, double** dist, double** rep, double** dv, int32_t** orig) {
+  char* w = (char*)workspace;
+  *dist = (double*)w; w += align256((size_t)N * N * 8);
+  *rep = (double*)w;  w += align256((size_t)N * 8);
+  *dv = (double*)w;   w += align256((size_t)N * 8);
+  *orig = (int32_t*)w;
+}
+extern "C" size_t gpsr_active_sample_workspace_bytes(int N) {
+  if (N < 2) return 0;
+  return align256((size_t)N * N * 8) + 2 * align256((size_t)N * 8) + align256((size_t)N * 4);
+}
+extern "C" int gpsr_active_sample(const double* data, int N, int D, int K, int n_pick, double bandwidth, double w_rep,
+                                  double w_div, int32_t* out_idx, double* rep_out, void* workspace,
+                                  size_t workspace_bytes, void* stream) {
+  if (n_pick == 0) return 0;
+  if (!data || !out_idx || !workspace) return arg_fail("null pointer");
+  if (N < 2 || N > 46340) return arg_fail("active_sample: N must be in 2..46340");
+  if (D < 1 || D > AS_MAXD) return arg_fail("active_sample: D must be in 1..128 (numpy's unrolled summation block)");
+  if (K < 1 || K > AS_MAXK || K >= N) return arg_fail("active_sample: K must be in 1..64 and below N");
+  if (n_pick < 0 || n_pick > N) return arg_fail("active_sample: n_pick must be in 0..N");
+  if (!(bandwidth > 0.0)) return arg_fail("active_sample: bandwidth must be positive");
+  if (workspace_bytes < gpsr_active_sample_workspace_bytes(N)) return arg_fail("workspace too small");
+  double *dist, *rep, *dv; int32_t* orig;
+  as_carve(workspace, N, &dist, &rep, &dv, &orig);
+  hipStream_t st = (hipStream_t)stream;
+  const unsigned g = (unsigned)((N + 15) / 16);
+  hipLaunchKernelGGL(k_as_dist, dim3(g, g), dim3(256), (size_t)(2 * 16 * (D | 1)) * sizeof(double), st, data, N, D, dist);
+  CHECK_LAUNCH("k_as_dist");
+  const double two_bw = 2 * bandwidth;   // agpr.py:128,222 divide by (2*self.bandwidth)
+  hipLaunchKernelGGL(k_as_rep, dim3((unsigned)N), dim3(256), 0, st, dist, N, K, two_bw, rep);
+  CHECK_LAUNCH("k_as_rep");
+  hipLaunchKernelGGL(k_as_greedy, dim3(1), dim3(AS_THREADS), 0, st, dist, rep, N, n_pick, two_bw, w_rep, w_div, orig, dv,
+                     out_idx);
+  CHECK_LAUNCH("k_as_greedy");
+  if (rep_out) {
+    hipError_t e = hipMemcpyAsync(rep_out, rep, (size_t)N * 8, hipMemcpyDeviceToDevice, st);
+    if (e != hipSuccess) return hip_fail(e, "active_sample: copy of the scores");
+  }
+  return 0;
+}
+
 #ifdef GPSR_UPD_TRACE
 // debug build only (tools/upd_trace.py): read (and clear) the k_update2 cycle counters
 extern "C" int gpsr_debug_upd_trace(unsigned long long* out8) {

@@ -2236,3 +2236,155 @@ k_metrics_final(const unsigned long long* __restrict__ sse_part, const double* _
     out[2] = mse;
   }
 }
+
+// ------------------------------------------------ AGPR training-set selection (agpr.py:120-137, 211-222)
+// The reference builds an [N][N] matrix of squared distances between candidate rows (bicubic 7x7 patch + HR centre
+// pixel, D = 50), scores every row by the mean of exp(-d / 2bw) over its K nearest neighbours ("representativeness"),
+// then picks floor(ratio * N) rows greedily: argmax of w_rep * rep + w_div * div, div = min over the rows chosen so far
+// of -exp(-d / 2bw).  Two habits of the reference are kept because they decide which rows are chosen: rep is indexed
+// by a row's POSITION IN THE SHRINKING POOL (np.delete shifts the pool, the score array stays), and the sums run in
+// numpy's order (np_sum below), so the distances -- and through them every tie -- are those numpy produces.
+//
+// numpy's float64 add.reduce over a contiguous axis of n <= 128 elements (pairwise_sum's unrolled block): eight
+// interleaved partial sums, a fixed tree over them, the n % 8 tail added one by one; plain loop below 8 elements.
+template <class F>
+__device__ __forceinline__ double np_sum(int n, F term) {
+  if (n < 8) {
+    double r = 0.0;
+    for (int i = 0; i < n; ++i) r += term(i);
+    return r;
+  }
+  double r[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = term(j);
+  int i = 8;
+  for (; i < n - (n % 8); i += 8) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) r[j] += term(i + j);
+  }
+  double res = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+  for (; i < n; ++i) res += term(i);
+  return res;
+}
+
+// dist[i][j] = sum_k (x_ik - x_jk)^2 (agpr.py:123), +inf on the diagonal (:124).  16 x 16 pairs per workgroup, the
+// 2 x 16 rows staged in LDS (row length padded to an odd number of doubles: conflict-free column walks).
+#define AS_MAXD 128
+__global__ void __launch_bounds__(256)
+k_as_dist(const double* __restrict__ data, int N, int D, double* __restrict__ dist) {
+  extern __shared__ double as_rows[];
+  const int ld = D | 1;
+  double* ri = as_rows;
+  double* rj = as_rows + 16 * ld;
+  const int i0 = blockIdx.y * 16, j0 = blockIdx.x * 16;
+  for (int e = threadIdx.x; e < 16 * D; e += 256) {
+    const int r = e / D, k = e - r * D;
+    ri[r * ld + k] = (i0 + r < N) ? data[(size_t)(i0 + r) * D + k] : 0.0;
+    rj[r * ld + k] = (j0 + r < N) ? data[(size_t)(j0 + r) * D + k] : 0.0;
+  }
+  __syncthreads();
+  const int ti = threadIdx.x >> 4, tj = threadIdx.x & 15;
+  const int i = i0 + ti, j = j0 + tj;
+  if (i >= N || j >= N) return;
+  const double* a = ri + ti * ld;
+  const double* b = rj + tj * ld;
+  const double s = np_sum(D, [&](int k) { const double t = a[k] - b[k]; return t * t; });
+  dist[(size_t)i * N + j] = (i == j) ? __builtin_inf() : s;
+}
+
+// rep[i] = mean over the K smallest entries of row i of exp(-d / (2 bw)) (agpr.py:126-128): K rounds of "smallest
+// (value, column) pair above the previous one", so equal distances are taken in column order (their values, and
+// with them the mean, do not depend on the order numpy's unstable argsort would give them).
+#define AS_MAXK 64
+__global__ void __launch_bounds__(256)
+k_as_rep(const double* __restrict__ dist, int N, int K, double two_bw, double* __restrict__ rep) {
+  __shared__ double sv[256];
+  __shared__ int sc[256];
+  __shared__ double nd[AS_MAXK];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  const double* row = dist + (size_t)i * N;
+  double pv = -1.0;   // distances are >= 0: nothing is excluded in the first round
+  int pc = -1;
+  for (int r = 0; r < K; ++r) {
+    double bv = __builtin_inf();
+    int bc = 0x7fffffff;
+    for (int c = tid; c < N; c += 256) {
+      const double v = row[c];
+      const bool after = v > pv || (v == pv && c > pc);
+      if (after && (v < bv || (v == bv && c < bc))) { bv = v; bc = c; }
+    }
+    sv[tid] = bv; sc[tid] = bc;
+    __syncthreads();
+    for (int o = 128; o > 0; o >>= 1) {
+      if (tid < o) {
+        const double v = sv[tid + o];
+        const int c = sc[tid + o];
+        if (v < sv[tid] || (v == sv[tid] && c < sc[tid])) { sv[tid] = v; sc[tid] = c; }
+      }
+      __syncthreads();
+    }
+    pv = sv[0]; pc = sc[0];
+    if (tid == 0) nd[r] = pv;
+    __syncthreads();
+  }
+  if (tid == 0) {
+    const double s = np_sum(K, [&](int k) { return exp(-nd[k] / two_bw); });
+    rep[i] = s / (double)K;
+  }
+}
+
+// The greedy loop (agpr.py:132-137) as ONE workgroup: the pool lives in global memory as orig[pos] (row index) and
+// dv[pos] (running diversity), both shifted left past the chosen position every round exactly as np.delete does.
+#define AS_THREADS 1024
+__global__ void __launch_bounds__(AS_THREADS)
+k_as_greedy(const double* __restrict__ dist, const double* __restrict__ rep, int N, int n_pick, double two_bw,
+            double w_rep, double w_div, int32_t* __restrict__ orig, double* __restrict__ dv,
+            int32_t* __restrict__ out_idx) {
+  __shared__ double sv[AS_THREADS];
+  __shared__ int sp[AS_THREADS];
+  const int tid = threadIdx.x;
+  for (int p = tid; p < N; p += AS_THREADS) { orig[p] = p; dv[p] = 0.0; }   // get_diversity: 0 while nothing is chosen
+  __syncthreads();
+  for (int it = 0; it < n_pick; ++it) {
+    const int len = N - it;
+    // np.argmax: the first position holding the maximum
+    double bv = -__builtin_inf();
+    int bp = 0x7fffffff;
+    for (int p = tid; p < len; p += AS_THREADS) {
+      const double s = w_rep * rep[p] + w_div * dv[p];
+      if (s > bv) { bv = s; bp = p; }
+    }
+    sv[tid] = bv; sp[tid] = bp;
+    __syncthreads();
+    for (int o = AS_THREADS / 2; o > 0; o >>= 1) {
+      if (tid < o) {
+        const double v = sv[tid + o];
+        const int p = sp[tid + o];
+        if (v > sv[tid] || (v == sv[tid] && p < sp[tid])) { sv[tid] = v; sp[tid] = p; }
+      }
+      __syncthreads();
+    }
+    int j = sp[0];
+    if (j >= len) j = 0;   // every score NaN: np.argmax answers with the first NaN; position 0 keeps the loop finite
+    const int pick = orig[j];
+    __syncthreads();        // everyone has read sp[0] and orig[j] before the pool moves
+    if (tid == 0) out_idx[it] = pick;
+    const double* drow = dist + (size_t)pick * N;
+    // np.delete + the new minimum, in rounds of AS_THREADS positions: a round reads positions q (+1 past j) and
+    // writes positions q; its reads of q + 1 all happen before the barrier, the next round's writes after it
+    for (int base = 0; base < len - 1; base += AS_THREADS) {
+      const int p = base + tid;
+      int o = 0;
+      double d = 0.0;
+      if (p < len - 1) {
+        const int q = p + (p >= j ? 1 : 0);
+        o = orig[q];
+        const double cand = -exp(-drow[o] / two_bw);
+        d = (it == 0) ? cand : fmin(dv[q], cand);
+      }
+      __syncthreads();
+      if (p < len - 1) { orig[p] = o; dv[p] = d; }
+      __syncthreads();
+    }
+  }
+}

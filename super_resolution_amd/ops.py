@@ -356,6 +356,20 @@ def metrics(a, b, crop):
     return out
 
 
+def active_sample(data, K, n_pick, bandwidth, w_rep, w_div):
+    """[N,D] float64 device rows -> (int32 [n_pick] chosen row indices in the order chosen, float64 [N]
+    representativeness scores): the training-set selection of agpr.py:120-137 (gpsr_active_sample)."""
+    lib = _lib.load()
+    N, D = data.shape
+    nbytes = lib.gpsr_active_sample_workspace_bytes(N)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=data.device)
+    idx = torch.empty(n_pick, dtype=torch.int32, device=data.device)
+    rep = torch.empty(N, dtype=torch.float64, device=data.device)
+    _lib.check(lib.gpsr_active_sample(_p(data, torch.float64), N, D, int(K), int(n_pick), float(bandwidth), float(w_rep), float(w_div),
+                                      _p(idx, torch.int32), _p(rep), _p(ws), nbytes, _stream()), "gpsr_active_sample")
+    return idx, rep
+
+
 # ------------------------------------------------------------ kernel timing
 PROF_TAGS = ("update", "panel", "pivot", "build", "grad1", "grad2", "predict", "update_last", "update2", "update_sel")
 

@@ -95,3 +95,72 @@ def test_agpr_filter_equals_per_pixel_gp_mean(golden_dir):
                                   torch.tensor(np.ascontiguousarray(win)).float().double(), ogp.LINEAR)
     assert np.abs(out[3:-3, 3:-3].reshape(-1) - mean.numpy()).max() < 1e-8
     assert np.array_equal(out[:3], img[:3]) and np.array_equal(out[:, -3:], img[:, -3:])
+
+
+def _candidate_rows(N, seed, D=50):
+    """Candidate rows shaped like agpr.py:113-118: 7x7 windows of a smooth image + one more pixel, np.unique'd."""
+    rng = np.random.default_rng(seed)
+    img = natural_image(120, 130, seed)
+    rows = []
+    for _ in range(N):
+        y, x = rng.integers(3, 117), rng.integers(3, 127)
+        rows.append(np.concatenate((img[y - 3:y + 4, x - 3:x + 4].reshape(-1)[:D - 1], [img[y, x] + 0.01 * rng.random()])))
+    return np.unique(np.array(rows), axis=0)
+
+
+@pytest.mark.parametrize("N,K,n_pick,seed", [(300, 10, 30, 0), (257, 3, 257, 1), (640, 10, 64, 2)])
+def test_active_sampling_vs_oracle(N, K, n_pick, seed):
+    """gpsr_active_sample against the oracle's line-by-line restatement of agpr.py:120-137 (which runs the
+    reference's own numpy calls): the SAME rows in the SAME order, scores to a few ulp (device exp vs numpy exp)."""
+    from super_resolution_amd import ops
+    data = _candidate_rows(N, seed)
+    n = len(data)
+    n_pick = min(n_pick, n)
+    want_idx, want_rows, want_rep, bw = oagpr.active_sampling(data, K=K, n_pick=n_pick)
+    assert bw == 0.2 * (n - 1) / 2          # the median of np.where's index arrays, whatever the data
+    idx, rep = ops.active_sample(to_dev(data), K, n_pick, bw, 0.2, 1 - 0.2)
+    idx, rep = idx.cpu().numpy(), rep.cpu().numpy()
+    assert np.abs(rep / want_rep - 1).max() < 1e-14
+    assert np.array_equal(idx, want_idx)
+    assert np.array_equal(data[idx], want_rows)
+
+
+def test_active_sampling_full_size_and_drop_in():
+    """N = 5000 candidates, 500 picks (the reference's constants): the drop-in's _active_sampling against a
+    vectorised numpy running-minimum form of the same loop (distances from numpy's own broadcast sum, in row
+    blocks), plus the properties the loop guarantees."""
+    from super_resolution_amd import agpr
+    data = _candidate_rows(5000, 7)
+    n = len(data)
+    a = agpr.AGPRSuperResolution.__new__(agpr.AGPRSuperResolution)
+    chosen = a._active_sampling(data)
+    idx = a.active_indices
+    assert len(chosen) == 500 and len(set(idx.tolist())) == 500 and a.bandwidth == 0.2 * (n - 1) / 2
+    dist = np.empty((n, n))
+    for r0 in range(0, n, 100):
+        dist[r0:r0 + 100] = np.sum((data[r0:r0 + 100, None, :] - data[None, :, :]) ** 2, axis=-1)
+    np.fill_diagonal(dist, np.inf)
+    near = np.sort(dist, axis=1)[:, :agpr.K]
+    rep = np.mean(np.exp(-near / (2 * a.bandwidth)), axis=-1)
+    assert np.abs(a.representativeness_scores / rep - 1).max() < 1e-14
+    pool = np.arange(n)
+    div = np.zeros(n)
+    for it in range(500):
+        j = int(np.argmax(0.2 * rep[:len(pool)] + (1 - 0.2) * div))
+        assert idx[it] == pool[j], f"pick {it}"
+        cand = -np.exp(-dist[pool[j]] / (2 * a.bandwidth))
+        pool = np.delete(pool, j)
+        div = np.delete(div, j)
+        div = cand[pool] if it == 0 else np.minimum(div, cand[pool])
+    assert np.array_equal(np.array(chosen), data[idx])
+
+
+def test_active_sampling_rejects_bad_sizes():
+    from super_resolution_amd import _lib, ops
+    data = to_dev(_candidate_rows(50, 3))
+    with pytest.raises(_lib.GpsrError):
+        ops.active_sample(data, 64, 5, 1.0, 0.2, 0.8)         # K >= N
+    with pytest.raises(_lib.GpsrError):
+        ops.active_sample(data, 5, len(data) + 1, 1.0, 0.2, 0.8)
+    with pytest.raises(_lib.GpsrError):
+        ops.active_sample(data, 5, 5, 0.0, 0.2, 0.8)          # bandwidth
