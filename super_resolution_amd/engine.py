@@ -51,6 +51,23 @@ def _geometry(H, W, s, p, stride_percentage):
     return rows, cols, locs
 
 
+def owned_jobs(shapes, p, stride_percentage, shard, chained):
+    """Which jobs (images of LR shape (H, W)) this rank fits patches of -- the table predict_pixels_batch itself
+    derives: a contiguous slice of the global patch list (independent GPs) or whole chains dealt out longest first."""
+    from . import dist as gdist
+    if shard is None:
+        return [True] * len(shapes)
+    rank, world = shard
+    stride = int((p - 2) * stride_percentage)
+    lens = [len(axis_starts(H, p, stride)) * len(axis_starts(W, p, stride)) for H, W in shapes]
+    if chained:
+        owner = gdist.deal_chains(lens, world)
+        return [owner[j] == rank for j in range(len(shapes))]
+    offs = np.concatenate([[0], np.cumsum(lens)])
+    lo, hi = gdist.shard_range(int(offs[-1]), rank, world)
+    return [bool(lens[j]) and lo < offs[j + 1] and hi > offs[j] for j in range(len(shapes))]
+
+
 def training_indices(p, use_all_pixels=True):
     """gprsr.py:137-140."""
     if use_all_pixels:
@@ -145,7 +162,7 @@ class BatchedGP:
 
 
 def predict_pixels_batch(jobs, s, p, gp, stride_percentage=0.9, use_all_pixels=True, mode=ops.AVERAGE,
-                         chain_carry=None, stats=None, shard=None):
+                         chain_carry=None, stats=None, shard=None, recombine="all"):
     """jobs: list of (training_input, training_target, test_input) device float64
     images (gprsr.py:126).  All patches of all jobs form ONE batch of GPs.
     Returns the list of recombined, clipped HR images.
@@ -158,15 +175,25 @@ def predict_pixels_batch(jobs, s, p, gp, stride_percentage=0.9, use_all_pixels=T
     chains -- this rank fits whole jobs (a chain is serial; the jobs are dealt out longest first).  The
     predicted patch interiors (+ raw hyper-parameters and flags, packed into the same rows) are exchanged
     with ONE all-gather (RCCL) before recombination -- the only collective on the path.
+
+    recombine="owned" (sharded runs): only the jobs this rank fitted patches of are recombined; the others come
+    back as None.  A rank needs the phase-1 image of a job only to gather its own phase-2 patches of that job
+    (the sharding is the same in both phases), so with many images per call -- N copies of a dataset on N
+    ranks -- every rank skips the image stages of the other ranks' images instead of repeating them.  A job
+    this rank owns nothing of may then also be handed in with training_input / test_input = None (its geometry
+    comes from training_target, which the caller always has).
     """
     from . import dist as gdist
-    dev = jobs[0][0].device
+    dev = jobs[0][1].device
     tidx = torch.as_tensor(training_indices(p, use_all_pixels)).to(dev)
     geo = []
+    assert recombine in ("all", "owned")
     for tin, ttg, tst in jobs:
-        assert tin.shape == ttg.shape
-        assert tst.shape[0] == tin.shape[0] * s and tst.shape[1] == tin.shape[1] * s
-        H, W = tin.shape
+        H, W = ttg.shape
+        if tin is not None:    # None: a job of another rank's share whose phase-1 image this rank skipped
+            assert tin.shape == ttg.shape
+        if tst is not None:
+            assert tst.shape[0] == H * s and tst.shape[1] == W * s
         assert p <= H and p <= W, f"Patch size {p} is too big for image size {(H, W)}"
         rows, cols, locs = _geometry(H, W, s, p, stride_percentage)
         geo.append((H, W, rows, cols, locs))
@@ -193,6 +220,7 @@ def predict_pixels_batch(jobs, s, p, gp, stride_percentage=0.9, use_all_pixels=T
     for j, ((tin, ttg, tst), (H, W, rows, cols, locs)) in enumerate(zip(jobs, geo)):
         sel = mine[(mine >= offs[j]) & (mine < offs[j + 1])] - offs[j]
         if sel.size:
+            assert tin is not None and tst is not None, f"job {j}: this rank owns patches of an image it was not given"
             X, y, Xs = ops.gather(tin, ttg, tst, s, p, torch.as_tensor(np.ascontiguousarray(locs[sel])).to(dev), tidx)
             Xl.append(X); yl.append(y); Xsl.append(Xs)
     if Xl:
@@ -228,6 +256,9 @@ def predict_pixels_batch(jobs, s, p, gp, stride_percentage=0.9, use_all_pixels=T
         stats.flags.append(flags)
     outs = []
     for j, ((tin, ttg, tst), (H, W, rows, cols, locs)) in enumerate(zip(jobs, geo)):
+        if tst is None or (recombine == "owned" and not np.any((mine >= offs[j]) & (mine < offs[j + 1]))):
+            outs.append(None)
+            continue
         out = ops.combine(pred[offs[j]:offs[j + 1]], tst, H, W, s, p, torch.as_tensor(rows).to(dev),
                           torch.as_tensor(cols).to(dev), mode, clip=True)
         outs.append(out)

@@ -72,8 +72,13 @@ class GPRSR:
     For RBF the three coincide."""
 
     def __init__(self, scaling_factor, used_kernel=matern52_kernel, color_mode=ColorSpace.YUV, *,
-                 warm_start="chain", iters=50, shard=None, max_workspace_bytes=48 << 30):
+                 warm_start="chain", iters=50, shard=None, max_workspace_bytes=48 << 30, outputs="all"):
         assert warm_start in ("independent", "chain", "chain_per_image")
+        assert outputs in ("all", "owned")
+        # outputs (sharded runs only): "all" = every rank returns every HR image; "owned" = a rank returns the
+        # images it fitted patches of and None for the others (data-parallel deployments, bench.py's weak scaling:
+        # the ranks then skip recombination and image stages of each other's images in both phases)
+        self.outputs = outputs
         self.scaling_factor = scaling_factor
         self.current_scaling_factor = None
         self.used_kernel = used_kernel
@@ -85,6 +90,7 @@ class GPRSR:
         self.check_failures = True
         self._carry = None          # [n_images,4] float32 device tensor while a chained call runs
         self._scoped_carry = None   # chain_per_image: the carry of the image apply() is working on (BGR: 3 channels)
+        self._last_round = True     # x4 = x2 o x2: False while the first x2 round runs
         self._gp = engine.BatchedGP(kernel_id_of(used_kernel), iters=iters, lr=LEARNING_RATE,
                                     max_workspace_bytes=max_workspace_bytes)
 
@@ -174,39 +180,49 @@ class GPRSR:
         self._carry = carry
         try:
             scaling_factor = self.scaling_factor
+            self._last_round = False
             while scaling_factor >= 4:
                 scaling_factor /= 2
-                imgs = self._do_algorithm(imgs, 2)
+                imgs = self._do_algorithm(imgs, 2)   # every rank needs every intermediate image: the next round starts from it
+            self._last_round = True
             return self._do_algorithm(imgs, scaling_factor)
         finally:
             self._carry = None
 
     def _do_algorithm(self, imgs, scaling_factor):
         self.current_scaling_factor = scaling_factor
-        blurred_high = self._upsample(imgs)
-        blurred_low = [self._blur_downsample(b) for b in blurred_high]
-        return self._predict_pixels(list(zip(blurred_low, imgs, blurred_high)))
+        # outputs="owned": a rank then needs the phase-1 image only where it has phase-2 patches of its own (None
+        # elsewhere); with outputs="all" it recombines every image in phase 2, on top of the phase-1 image
+        rc = self.outputs if self._last_round else "all"
+        blurred_high = self._upsample(imgs, recombine=rc)
+        blurred_low = [None if b is None else self._blur_downsample(b) for b in blurred_high]
+        return self._predict_pixels(list(zip(blurred_low, imgs, blurred_high)), recombine=rc)
 
     def _s_int(self):
         s = self.current_scaling_factor
         assert float(s) == int(s), "the patch pipeline needs an integer step factor (2 or 3)"
         return int(s)
 
-    def _upsample(self, imgs):
+    def _upsample(self, imgs, recombine="all"):
         s = self.current_scaling_factor
-        bic = [imgproc.resize_cubic(im, fx=s, fy=s) for im in imgs]
-        return self._predict_pixels(list(zip(imgs, imgs, bic)))
+        own = [True] * len(imgs)
+        if recombine == "owned" and self.shard is not None:   # the bicubic image of another rank's image is never read
+            own = engine.owned_jobs([tuple(im.shape) for im in imgs], int(s * 10), STRIDE_PERCENTAGE, self.shard,
+                                    self._carry is not None)
+        bic = [imgproc.resize_cubic(im, fx=s, fy=s) if o else None for im, o in zip(imgs, own)]
+        return self._predict_pixels(list(zip(imgs, imgs, bic)), recombine=recombine)
 
     def _blur_downsample(self, img):
         s = self.current_scaling_factor
         return imgproc.resize_linear(imgproc.gaussian_blur(img, 5, 0), 1 / s, 1 / s)
 
-    def _predict_pixels(self, jobs):
+    def _predict_pixels(self, jobs, recombine="all"):
         s = self._s_int()
         p = int(self.current_scaling_factor * 10)
         mode = PATCH_INTERPOLATION.value
         return engine.predict_pixels_batch(jobs, s, p, self._gp, STRIDE_PERCENTAGE, USE_ALL_PIXELS_FOR_TRAINING,
-                                           mode, chain_carry=self._carry, stats=self.stats, shard=self.shard)
+                                           mode, chain_carry=self._carry, stats=self.stats, shard=self.shard,
+                                           recombine=recombine if self.shard is not None else "all")
 
     # ------------------------------------------------------------------ reference-named numpy methods
     def _to_dev(self, a):

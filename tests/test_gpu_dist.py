@@ -59,6 +59,13 @@ sharded = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, warm_start="independ
 if rank == 0:
     whole = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, warm_start="independent").apply_for_channel_device(dimgs)
     assert all(torch.equal(a, b) for a, b in zip(sharded, whole)), "sharded != unsharded"
+# outputs="owned": a rank returns only the images it fitted patches of, and skips the stages of the others
+owned = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, warm_start="independent", shard=(rank, world), outputs="owned").apply_for_channel_device(dimgs)
+assert any(o is None for o in owned) and any(o is not None for o in owned), [o is None for o in owned]
+assert all(o is None or torch.equal(o, a) for o, a in zip(owned, sharded)), "owned != all"
+have = torch.tensor([float(o is not None) for o in owned]); dist.all_reduce(have)
+assert bool((have >= 1).all()), "an image nobody returned"
+if rank == 0:
     sys.stdout.write("shard-ok\n")
 dist.barrier()
 dist.destroy_process_group()
@@ -77,7 +84,7 @@ def test_two_ranks_on_one_gpu_sharded_equals_unsharded(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29631", str(script)],
                        capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and "shard-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "shard-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-8000:]
 
 
 CHILD3 = r"""
@@ -98,6 +105,9 @@ sharded = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start="chain_pe
 if rank == 0:
     whole = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start="chain_per_image").apply_for_channel_device(dimgs)
     assert all(torch.equal(a, b) for a, b in zip(sharded, whole)), "sharded != unsharded"
+owned = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start="chain_per_image", shard=(rank, world), outputs="owned").apply_for_channel_device(dimgs)
+assert sum(o is not None for o in owned) == 7 and all(o is None or torch.equal(o, a) for o, a in zip(owned, sharded)), "owned != all"
+if rank == 0:
     sys.stdout.write("chain-shard-ok\n")
 dist.barrier()
 dist.destroy_process_group()
@@ -117,4 +127,4 @@ def test_two_ranks_on_one_gpu_chained_mode_equals_one_rank(tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29633", str(script)],
                        capture_output=True, text=True, timeout=600, env=env)
-    assert r.returncode == 0 and "chain-shard-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]
+    assert r.returncode == 0 and "chain-shard-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-8000:]

@@ -280,6 +280,26 @@ c3 = torch.zeros((1, 4))
 o1 = engine.predict_pixels_batch(small, 2, 20, FakeGP(), chain_carry=c3, shard=(rank, world))
 o2 = engine.predict_pixels_batch(small, 2, 20, FakeGP(), chain_carry=torch.zeros((1, 4)), shard=None)
 assert torch.equal(o1[0], o2[0])
+# recombine="owned": two copies of the two images on two ranks -> the patch slices are copy-aligned, a rank recombines
+# its own copy only and may be handed None for the inputs of the other rank's images (what GPRSR does in phase 2)
+jobs4 = jobs + [tuple(t.clone() for t in j) for j in jobs]
+own = engine.owned_jobs([tuple(j[1].shape) for j in jobs4], 20, 0.9, (rank, world), False)
+assert own == ([True, True, False, False] if rank == 0 else [False, False, True, True]), own
+ref4 = engine.predict_pixels_batch(jobs4, 2, 20, FakeGP(), shard=None)
+sparse = [j if o else (None, j[1], None) for j, o in zip(jobs4, own)]
+upsample_like = [j if o else (j[0], j[1], None) for j, o in zip(jobs4, own)]
+for given in (jobs4, sparse, upsample_like):
+    o4 = engine.predict_pixels_batch(given, 2, 20, FakeGP(), shard=(rank, world), recombine="owned")
+    for o, r, mine_ in zip(o4, ref4, own):
+        assert (o is None) == (not mine_) and (o is None or torch.equal(o, r))
+ownc = engine.owned_jobs([tuple(j[1].shape) for j in jobs4], 20, 0.9, (rank, world), True)
+assert sum(ownc) == 2
+c4 = torch.zeros((4, 4)); c5 = torch.zeros((4, 4))
+o4 = engine.predict_pixels_batch(jobs4, 2, 20, FakeGP(), chain_carry=c4, shard=(rank, world), recombine="owned")
+r4 = engine.predict_pixels_batch(jobs4, 2, 20, FakeGP(), chain_carry=c5, shard=None)
+for o, r, mine_ in zip(o4, r4, ownc):
+    assert (o is None) == (not mine_) and (o is None or torch.equal(o, r))
+assert torch.equal(c4, c5)
 dist.barrier()
 sys.stdout.write("rank%dok\n" % rank); sys.stdout.flush()
 '''
