@@ -441,12 +441,14 @@ static int launch_op(const Op& op, const Batch& h, const FitShape& c) {
 }
 
 static int ensure_lds_attrs() {
-  static bool done = false;
-  if (!done) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_pivot, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)PIVOT_LDS_BYTES);
+  static bool done[64] = {};   // the attribute belongs to the kernel's code object on ONE device: once per device
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  if (dev < 0 || dev >= 64 || !done[dev]) {
+    e = hipFuncSetAttribute((const void*)k_pivot, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIVOT_LDS_BYTES);
     if (e != hipSuccess) return hip_fail(e, "pivot lds attr");
-    done = true;
+    if (dev >= 0 && dev < 64) done[dev] = true;
   }
   return 0;
 }
