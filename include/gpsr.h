@@ -289,7 +289,9 @@ int gpsr_axpy(const double* a, const double* b, double alpha, double* dst, size_
  *   gpsr_yuv2bgr     cv.merge + cv.cvtColor(COLOR_YUV2BGR)                         gprsr.py:62-63
  *   gpsr_bgr2ycrcb / gpsr_ycrcb2bgr   the same for YCrCb                           agpr.py:150-156
  *   gpsr_resample_u8 cv.resize(INTER_CUBIC) on a uint8 plane: 11-bit fixed-point taps (xa, ya = cvRound(coef*2048),
- *                    host tables [n][4] as for gpsr_resample), (x + 2^21) >> 22, saturated      gprsr.py:60-61, agpr.py:152-153
+ *                    host tables [n][4] as for gpsr_resample), integer horizontal pass; vertical pass as OpenCV's
+ *                    AVX2 loop: float32 fused multiply-adds, ties to even, in column steps of 16, the tail columns
+ *                    (x + 2^21) >> 22; saturated (pinned by the reference's colour outputs)   gprsr.py:60-61, agpr.py:152-153
  * bgr: [npx][3] interleaved (cv.imread layout); planes: [npx].
  */
 int gpsr_bgr2gray(const uint8_t* bgr, uint8_t* gray, size_t npx, void* stream);

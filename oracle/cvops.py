@@ -61,7 +61,7 @@ def _cubic_tables(n_dst, n_src, inv_scale):
 def resize_cubic(img, fx=None, fy=None, dsize=None):
     """cv.resize(INTER_CUBIC).  float64 images: float32 coefficients, float64
     accumulation, horizontal pass then vertical pass.  uint8 images: 11-bit
-    fixed-point coefficients, integer passes, (x + 2^21) >> 22, saturate."""
+    fixed-point coefficients, integer horizontal pass, float32 vertical pass (below), saturate."""
     H, W = img.shape
     if dsize is None:
         Wd, Hd = cv_round(W * fx), cv_round(H * fy)
@@ -78,12 +78,28 @@ def resize_cubic(img, fx=None, fy=None, dsize=None):
         hbuf = np.zeros((H, Wd), dtype=np.int64)
         for k in range(4):
             hbuf += src[:, xi[:, k]] * xa[None, :, k]
+        # Vertical pass as resize.cpp runs it on x86: VResizeCubicVec_32s8u covers the columns in steps of 16
+        # (AVX2) in float32, fma(s0,b0, fma(s1,b1, fma(s2,b2, s3*b3))) with b = beta / 2^22, rounded half to EVEN; the
+        # tail columns take the integer form (x + 2^21) >> 22 (half UP).  They differ on exact ties only.  Pinned:
+        # with the float form the chroma of the reference's own x2 / x4 colour outputs is reproduced on every
+        # pixel, with the integer form on all but a handful, with unfused multiply-adds or 32-column steps on all
+        # but one (tests/test_refpin.py): an AVX2 + FMA3 build.
         out = np.zeros((Hd, Wd), dtype=np.int64)
+        nvec = (Wd // 16) * 16
+        scale = np.float32(1.0) / np.float32(2048 * 2048)
         for r in range(Hd):
+            S = [hbuf[yi[r, k]] for k in range(4)]
             acc = np.zeros(Wd, dtype=np.int64)
             for k in range(4):
-                acc += hbuf[yi[r, k]] * ya[r, k]
-            out[r] = (acc + (1 << 21)) >> 22
+                acc += S[k] * ya[r, k]
+            row = (acc + (1 << 21)) >> 22
+            b = [np.float32(ya[r, k]) * scale for k in range(4)]
+            Sf = [s_[:nvec].astype(np.float32) for s_ in S]
+            f = Sf[3] * b[3]
+            for k in (2, 1, 0):   # fused multiply-add: the float32 product is exact in float64, one rounding to float32
+                f = (Sf[k].astype(np.float64) * np.float64(b[k]) + f.astype(np.float64)).astype(np.float32)
+            row[:nvec] = np.rint(f).astype(np.int64)
+            out[r] = row
         return np.clip(out, 0, 255).astype(np.uint8)
     src = img.astype(np.float64)
     xcd = xc.astype(np.float64)

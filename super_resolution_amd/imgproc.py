@@ -177,7 +177,7 @@ def ycrcb2bgr(Y, Cr, Cb):
 
 
 def resize_cubic_u8(img, fx=None, fy=None, dsize=None):
-    """cv.resize INTER_CUBIC on uint8 (chroma planes): 11-bit fixed-point taps."""
+    """cv.resize INTER_CUBIC on uint8 (chroma planes): 11-bit fixed-point taps, float32 vertical pass."""
     H, W = img.shape
     if dsize is None:
         Wd, Hd, isx, isy = cv_round(W * fx), cv_round(H * fy), fx, fy
@@ -190,5 +190,14 @@ def resize_cubic_u8(img, fx=None, fy=None, dsize=None):
     ya = np.rint(yw * 2048).astype(np.int64)
     src = img.astype(np.int64)
     hbuf = (src[:, xi] * xa[None, :, :]).sum(-1)                 # [H, Wd]
-    out = (hbuf[yi] * ya[:, :, None]).sum(1)                     # [Hd, Wd]
-    return np.clip((out + (1 << 21)) >> 22, 0, 255).astype(np.uint8)
+    out = ((hbuf[yi] * ya[:, :, None]).sum(1) + (1 << 21)) >> 22  # [Hd, Wd]: the tail columns of OpenCV's loop
+    # the columns OpenCV's SIMD loop covers (16 per step) are evaluated in float32 and rounded half to even
+    # (VResizeCubicVec_32s8u); same arithmetic as k_resample_u8
+    nvec = (Wd // 16) * 16
+    S = hbuf[yi][:, :, :nvec].astype(np.float32)                 # [Hd, 4, nvec]
+    b = ya.astype(np.float32) * np.float32(1.0 / (2048.0 * 2048.0))
+    f = S[:, 3] * b[:, 3, None]
+    for k in (2, 1, 0):   # fused multiply-adds (v_muladd on FMA3 builds): float32 products are exact in float64
+        f = (S[:, k].astype(np.float64) * b[:, k, None].astype(np.float64) + f.astype(np.float64)).astype(np.float32)
+    out[:, :nvec] = np.rint(f).astype(np.int64)
+    return np.clip(out, 0, 255).astype(np.uint8)

@@ -12,6 +12,18 @@ only sees the PNGs written here.
   Set14/image_SRF_3/img_001_SRF_3_GPR_{RBF,matern12}.png     -> refpin/x3_ref_{RBF,matern12}_001.png
         (three equal channels: GRAYSCALE runs; RBF has no chain, gprsr.py:167-172)
 The reference's three-equal-channel outputs are stored as 8-bit grey PNGs (one channel, no conversion).
+
+COLOUR outputs (stored as they are, RGB PNGs).  Their file names carry only the kernel tag; the settings that produced
+them were found by running the HIP path over the candidates (tools/refpin_colour_probe.py) -- each line below is the
+one combination that reproduces the file, the others are far off (20-70 % identical pixels):
+  Set14/image_SRF_2/img_001_SRF_2_GPR_matern12.png  -> refpin/x2_ref_matern12_yuv_001.png
+        YUV (gprsr.py:56-64), exponential kernel, the warm-start chain from a fresh process, AVERAGE: today's code path
+  Set14/image_SRF_2/img_00{1,2}_SRF_2_GPR_matern52.png -> refpin/x2_ref_matern52_yuv_00{1,2}.png
+  Set14/image_SRF_4/img_001_SRF_4_{LR,GPR_matern32}.png -> refpin/x4_lr_001.png, refpin/x4_ref_matern32_yuv_001.png
+  Set14/image_SRF_3/img_001_SRF_3_GPR_{matern32,linear}.png -> refpin/x3_ref_{matern32,linear}_yuv_001.png
+        YUV, BILINEAR patch interpolation (image_patches.py:67-70) and EVERY PATCH FROM THE INITIAL HYPER-PARAMETERS:
+        an earlier state of the reference in which the kernel was not yet a shared singleton -- exactly this
+        repo's warm_start="independent".  (x3 linear: chain / AVERAGE, like matern12.)  x4 runs x2 twice (gprsr.py:94-96).
 """
 import os
 import sys
@@ -46,4 +58,15 @@ for i in (1, 2):
 Image.fromarray(rgb(f"{REF}/image_SRF_3/img_001_SRF_3_LR.png")).save(f"{OUT}/x3_lr_001.png")
 for tag in ("RBF", "matern12"):
     save_grey3(f"{REF}/image_SRF_3/img_001_SRF_3_GPR_{tag}.png", f"x3_ref_{tag}_001.png")
+def save_rgb(src, dst):
+    Image.fromarray(rgb(src)).save(os.path.join(OUT, dst))
+
+
+save_rgb(f"{REF}/image_SRF_2/img_001_SRF_2_GPR_matern12.png", "x2_ref_matern12_yuv_001.png")
+for i in (1, 2):
+    save_rgb(f"{REF}/image_SRF_2/img_{i:03d}_SRF_2_GPR_matern52.png", f"x2_ref_matern52_yuv_{i:03d}.png")
+save_rgb(f"{REF}/image_SRF_4/img_001_SRF_4_LR.png", "x4_lr_001.png")
+save_rgb(f"{REF}/image_SRF_4/img_001_SRF_4_GPR_matern32.png", "x4_ref_matern32_yuv_001.png")
+for tag in ("matern32", "linear"):
+    save_rgb(f"{REF}/image_SRF_3/img_001_SRF_3_GPR_{tag}.png", f"x3_ref_{tag}_yuv_001.png")
 print("ok", sorted(os.listdir(OUT)))

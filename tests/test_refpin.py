@@ -77,3 +77,47 @@ def test_oracle_reproduces_the_references_x3_outputs(golden_dir, kid, tag):
     out = osr.OracleGPRSR(3, kid, "GRAYSCALE", chain=True).apply(_bgr(_load(golden_dir, "x3_lr_001.png")))
     ident, maxd = _stats(out[..., 0], _load(golden_dir, f"x3_ref_{tag}_001.png"))
     assert ident >= 0.999 and maxd <= 1
+
+
+# ---------------------------------------------------------------- the reference's COLOUR outputs (YUV mode)
+def _explained_by_chroma(ref_bgr, U, V):
+    """Share of pixels whose reference BGR value is yuv2bgr(Y, U, V) for SOME luma Y: a test of the colour stages and
+    of the uint8 bicubic chroma planes that needs no GP fit (a wrong U or V leaves no Y that reproduces all three
+    channels)."""
+    ok = np.zeros(ref_bgr.shape[:2], bool)
+    for Y in range(256):
+        ok |= (cvops.yuv2bgr(np.stack([np.full(U.shape, Y, np.uint8), U, V], -1)) == ref_bgr).all(-1)
+    return float(ok.mean())
+
+
+@pytest.mark.parametrize("s,lr,ref,bar", [(2, "x2_lr_001.png", "x2_ref_matern52_yuv_001.png", 1.0),
+                                          (2, "x2_lr_002.png", "x2_ref_matern52_yuv_002.png", 1.0),
+                                          (2, "x2_lr_001.png", "x2_ref_matern12_yuv_001.png", 1.0),
+                                          (4, "x4_lr_001.png", "x4_ref_matern32_yuv_001.png", 1.0),
+                                          (3, "x3_lr_001.png", "x3_ref_matern32_yuv_001.png", 0.99)])
+def test_colour_stages_and_uint8_bicubic_explain_the_references_colour_outputs(golden_dir, s, lr, ref, bar):
+    """cvops.bgr2yuv, the uint8 INTER_CUBIC resize (fixed-point taps, OpenCV's float32 vertical pass with ties to
+    even) and cvops.yuv2bgr against the reference's own YUV-mode outputs (gprsr.py:56-64): at x2 and x4 EVERY pixel of
+    the reference is yuv2bgr(some Y, our U, our V).  With the integer vertical pass ((x + 2^21) >> 22, ties up) a few
+    pixels per image are not.  At x3 1 % of the pixels are not: there the reference's planes are one level off
+    OpenCV's own fixed-point code (float arithmetic on unquantised taps explains 99.7 % -- an IPP-backed cv.resize);
+    recorded, not reproduced."""
+    yuv = cvops.bgr2yuv(_bgr(_load(golden_dir, lr)))
+    U = cvops.resize_cubic(np.ascontiguousarray(yuv[..., 1]), fx=s, fy=s)
+    V = cvops.resize_cubic(np.ascontiguousarray(yuv[..., 2]), fx=s, fy=s)
+    share = _explained_by_chroma(_bgr(_load(golden_dir, ref)), U, V)
+    print(f"{ref}: {100 * share:.4f} % of the pixels explained")
+    assert share >= bar
+
+
+@pytest.mark.skipif(not os.environ.get("GPSR_REFPIN_FULL"), reason="minutes of CPU; measured values in DESIGN.md section 2")
+def test_oracle_independent_bilinear_reproduces_the_references_x4_matern32_colour_output(golden_dir):
+    """The oracle in the configuration that produced img_001_SRF_4_GPR_matern32.png: YUV, Matern-3/2, x4 = x2 o x2,
+    BILINEAR recombination, every patch from the initial hyper-parameters (chain=False)."""
+    from oracle import patches as P
+    torch.set_num_threads(min(4, os.cpu_count() or 1))
+    o = osr.OracleGPRSR(4, ogp.MATERN32, "YUV", chain=False, patch_interpolation=P.BILINEAR)
+    out = o.apply(_bgr(_load(golden_dir, "x4_lr_001.png")))
+    ident, maxd = _stats(out, _bgr(_load(golden_dir, "x4_ref_matern32_yuv_001.png")))
+    print(f"oracle independent / BILINEAR vs the reference's x4 matern32 PNG: {100 * ident:.4f} % identical, max |diff| {maxd}")
+    assert ident >= 0.999 and maxd <= 2

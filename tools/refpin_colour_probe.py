@@ -1,0 +1,92 @@
+"""Exploration: which settings reproduce the reference's COLOUR output PNGs?  HIP path, one hypothesis per argument:
+    x<s>:<kernel tag>:<BGR|YUV|GRAYSCALE>:<chain|independent|chain_per_image>[:bilinear=1][:grid=1][:lr=..][:stride=..]
+       [:iters=..][:rbfinit=1|2|3][:noise0=1][:mean0=1][:ref=<png under tests/golden>][:lr=<png under tests/golden>]
+This is how the settings recorded in tests/golden/make_refpin_fixtures.py were found (round 2): e.g.
+    x2:matern52:YUV:chain -> 49 % identical pixels, x2:matern52:YUV:independent:bilinear=1 -> 100 %.
+Candidates that no tried combination reproduces (their files are not fixtures; pass ref= / lr= to a copy):
+img_001_SRF_2_GPR_{RBF,matern32,exponential}.png."""
+import os, sys, time
+import numpy as np, torch
+from PIL import Image
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from super_resolution_amd import kernels as K, gprsr
+from super_resolution_amd.gprsr import GPRSR, ColorSpace
+G = os.path.join(ROOT, "tests", "golden", "refpin")
+load = lambda n: np.array(Image.open(os.path.join(G, n)))
+bgr = lambda a: np.ascontiguousarray(a[..., ::-1])
+gprsr.DO_TIMING = False
+
+def report(tag, got, ref):
+    d = np.abs(got.astype(int) - ref.astype(int))
+    per = [f"{100 * (d[..., c] == 0).mean():.2f}" for c in range(3)]
+    print(f"{tag}: identical {100 * (d == 0).mean():.3f}% (B,G,R: {per})  <=1 {100 * (d <= 1).mean():.3f}%  max {d.max()}", flush=True)
+
+KERN = {"matern32": K.matern32_kernel, "matern52": K.matern52_kernel, "matern12": K.exponential_kernel,
+        "exponential": K.exponential_kernel, "RBF": K.rbf_kernel, "linear": K.linear_kernel}
+cases = sys.argv[1:] or ["x2:matern32:YUV:chain"]
+for case in cases:
+    parts = case.split(":")
+    sf, tag, mode, ws = parts[:4]
+    from super_resolution_amd.image_patches import PatchInterpolationMode
+    gprsr.USE_ALL_PIXELS_FOR_TRAINING, gprsr.LEARNING_RATE, gprsr.STRIDE_PERCENTAGE = True, 0.1, 0.9
+    gprsr.PATCH_INTERPOLATION = PatchInterpolationMode.AVERAGE
+    iters = 50
+    rbfinit = 0
+    noise0 = mean0 = 0
+    for o in parts[4:]:
+        k, v = o.split("=")
+        if k in ("ref", "lr"): continue
+        if k == "grid": gprsr.USE_ALL_PIXELS_FOR_TRAINING = not int(v)
+        if k == "lr": gprsr.LEARNING_RATE = float(v)
+        if k == "stride": gprsr.STRIDE_PERCENTAGE = float(v)
+        if k == "bilinear" and int(v): gprsr.PATCH_INTERPOLATION = PatchInterpolationMode.BILINEAR
+        if k == "iters": iters = int(v)
+        if k == "rbfinit": rbfinit = int(v)
+        if k == "noise0": noise0 = int(v)
+        if k == "mean0": mean0 = int(v)
+    s = int(sf[1:])
+    lr = bgr(load(f"x{s}_lr_001.png"))
+    refname = next((o.split("=")[1] for o in parts[4:] if o.startswith("ref=")), f"refpin/x{s}_ref_{tag}_yuv_001.png")
+    ref = np.array(Image.open(os.path.join(ROOT, "tests", "golden", refname)))
+    ref = np.stack([ref] * 3, -1) if ref.ndim == 2 else bgr(ref)
+    lrname = next((o.split("=")[1] for o in parts[4:] if o.startswith("lr=")), None)
+    if lrname:
+        lr = bgr(np.array(Image.open(os.path.join(ROOT, "tests", "golden", lrname)).convert("RGB")))
+    for k in KERN.values():
+        k.reset()
+    t0 = time.time()
+    from super_resolution_amd import ops as _ops
+    if not hasattr(_ops, "_orig_init"):
+        _ops._orig_init = _ops.init_hypers
+    if rbfinit == 1:      # the RBF branch's per-patch values (l = .223, outputscale = var(y)) for every kernel
+        _ops.init_hypers = lambda y, kid, a=0.0, b=0.0, carry=None: _ops._orig_init(y, _ops.RBF, a, b, None)
+    elif rbfinit == 2:    # only the lengthscale of the RBF branch
+        def _i2(y, kid, a=0.0, b=0.0, carry=None):
+            r = _ops._orig_init(y, _ops.RBF, a, b, None); r0 = _ops._orig_init(y, kid, a, b, None); r0[:, 3] = r[:, 3]; return r0
+        _ops.init_hypers = _i2
+    elif rbfinit == 3:    # only the outputscale
+        def _i3(y, kid, a=0.0, b=0.0, carry=None):
+            r = _ops._orig_init(y, _ops.RBF, a, b, None); r0 = _ops._orig_init(y, kid, a, b, None); r0[:, 2] = r[:, 2]; return r0
+        _ops.init_hypers = _i3
+    else:
+        _ops.init_hypers = _ops._orig_init
+    if noise0 or mean0:   # GPyTorch's defaults instead of gprsr.py:163-165's noise = 1e-3 / constant = mean(y)
+        base = _ops.init_hypers
+        def _nm(y, kid, a=0.0, b=0.0, carry=None, base=base, noise0=noise0, mean0=mean0):
+            r = base(y, kid, a, b, carry)
+            if noise0: r[:, 0] = 0.0
+            if mean0: r[:, 1] = 0.0
+            return r
+        _ops.init_hypers = _nm
+    try:
+        g = GPRSR(s, KERN[tag], ColorSpace[mode], warm_start=ws, iters=iters)
+        got = g.apply(lr)
+        report(f"{case} ({time.time() - t0:.1f}s)", got, ref)
+        os.makedirs(os.path.join(ROOT, "gpurun_out", "probe"), exist_ok=True)
+        np.save(os.path.join(ROOT, "gpurun_out", "probe", case.replace(":", "_").replace("/", "_") + ".npy"), got)
+        if s == 2 and os.path.exists(os.path.join(G, f"x2_ref_{tag}_yuv_002.png")) and ws == "chain":
+            got2 = g.apply(bgr(load("x2_lr_002.png")))
+            report(f"{case} img_002 continuing the chain ({time.time() - t0:.1f}s)", got2, bgr(load(f"x2_ref_{tag}_yuv_002.png")))
+    except Exception as e:
+        print(case, "failed:", repr(e)[:300], flush=True)
