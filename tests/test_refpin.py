@@ -113,7 +113,8 @@ def test_colour_stages_and_uint8_bicubic_explain_the_references_colour_outputs(g
 @pytest.mark.skipif(not os.environ.get("GPSR_REFPIN_FULL"), reason="minutes of CPU; measured values in DESIGN.md section 2")
 def test_oracle_independent_bilinear_reproduces_the_references_x4_matern32_colour_output(golden_dir):
     """The oracle in the configuration that produced img_001_SRF_4_GPR_matern32.png: YUV, Matern-3/2, x4 = x2 o x2,
-    BILINEAR recombination, every patch from the initial hyper-parameters (chain=False)."""
+    BILINEAR recombination, every patch from the initial hyper-parameters (chain=False).  Measured: 100.0000 % identical,
+    max |diff| 0 (340 s on 4 threads)."""
     from oracle import patches as P
     torch.set_num_threads(min(4, os.cpu_count() or 1))
     o = osr.OracleGPRSR(4, ogp.MATERN32, "YUV", chain=False, patch_interpolation=P.BILINEAR)
