@@ -69,4 +69,7 @@ save_rgb(f"{REF}/image_SRF_4/img_001_SRF_4_LR.png", "x4_lr_001.png")
 save_rgb(f"{REF}/image_SRF_4/img_001_SRF_4_GPR_matern32.png", "x4_ref_matern32_yuv_001.png")
 for tag in ("matern32", "linear"):
     save_rgb(f"{REF}/image_SRF_3/img_001_SRF_3_GPR_{tag}.png", f"x3_ref_{tag}_yuv_001.png")
+for i in (4, 5, 6, 8):   # more (small) images of the x3 Matern-3/2 loop over Set14: independent starts, any order
+    save_rgb(f"{REF}/image_SRF_3/img_{i:03d}_SRF_3_LR.png", f"x3_lr_{i:03d}.png")
+    save_rgb(f"{REF}/image_SRF_3/img_{i:03d}_SRF_3_GPR_matern32.png", f"x3_ref_matern32_yuv_{i:03d}.png")
 print("ok", sorted(os.listdir(OUT)))

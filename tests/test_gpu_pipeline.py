@@ -217,9 +217,10 @@ def test_set14_x3_chain_per_image_vs_oracle_chain_goldens(golden_dir):
         assert abs(cvops.ssim(hr[c:-c, c:-c], got[c:-c, c:-c]) - cvops.ssim(hr[c:-c, c:-c], want[c:-c, c:-c])) <= 0.001
     assert min(ident) > 0.999, ident
     assert all(int(f.sum()) == 0 for f in g.stats.flags)
-    # the reference's own committed img_001_SRF_3_GPR_matern52.png (settings unknown: not the first image of a fresh
-    # process, or another stride): the chained result is 99.4 % identical to it, max 1 level (independent starts: 71 %,
-    # max 42) -- a loose pin only; the tight ones are in tests/test_gpu_refpin.py
+    # the reference's own committed img_001_SRF_3_GPR_matern52.png IS this run (chained, first image of a fresh process:
+    # tests/test_gpu_refpin.py reproduces it on every pixel from the colour LR file).  Here the input is the grey fixture
+    # lr_001.png, which round 1 made with the 14-bit grey table (0.14 % of its pixels are one level off the 15-bit
+    # BGR2GRAY the reference applies), so the agreement stops at 99.4 %, max 1 level -- a loose pin only
     ref = load("refout_m52_001.png")
     dd = np.abs(outs[0].astype(int) - ref.astype(int))
     assert dd.max() <= 1 and (dd == 0).mean() > 0.99

@@ -164,6 +164,9 @@ def test_x3_matern32_and_linear_yuv_reproduce_the_references_colour_outputs(gold
     lr = _bgr(_load(golden_dir, "x3_lr_001.png"))
     out = _independent_bilinear(3, K.matern32_kernel, lr)
     _compare_colour(out, _load(golden_dir, "x3_ref_matern32_yuv_001.png"), 0.993, 3, "x3 matern32 YUV independent img_001")
+    for i in (4, 5, 6, 8):   # four more images of the same loop over Set14 (independent starts: the order is immaterial)
+        out = _independent_bilinear(3, K.matern32_kernel, _bgr(_load(golden_dir, f"x3_lr_{i:03d}.png")))
+        _compare_colour(out, _load(golden_dir, f"x3_ref_matern32_yuv_{i:03d}.png"), 0.985, 3, f"x3 matern32 YUV independent img_{i:03d}")
     K.linear_kernel.reset()
     try:
         out = gprsr.GPRSR(3, K.linear_kernel, gprsr.ColorSpace.YUV).apply(lr)

@@ -69,6 +69,8 @@ for case in cases:
         def _i3(y, kid, a=0.0, b=0.0, carry=None):
             r = _ops._orig_init(y, _ops.RBF, a, b, None); r0 = _ops._orig_init(y, kid, a, b, None); r0[:, 2] = r[:, 2]; return r0
         _ops.init_hypers = _i3
+    elif rbfinit == 4:    # the other kernels' initial values (raw 0) for RBF too
+        _ops.init_hypers = lambda y, kid, a=0.0, b=0.0, carry=None: _ops._orig_init(y, _ops.MATERN52, a, b, None)
     else:
         _ops.init_hypers = _ops._orig_init
     if noise0 or mean0:   # GPyTorch's defaults instead of gprsr.py:163-165's noise = 1e-3 / constant = mean(y)
