@@ -292,6 +292,9 @@ int gpsr_axpy(const double* a, const double* b, double alpha, double* dst, size_
  *                    host tables [n][4] as for gpsr_resample), integer horizontal pass; vertical pass as OpenCV's
  *                    AVX2 loop: float32 fused multiply-adds, ties to even, in column steps of 16, the tail columns
  *                    (x + 2^21) >> 22; saturated (pinned by the reference's colour outputs)   gprsr.py:60-61, agpr.py:152-153
+ *   gpsr_sepfilter_u8 cv.GaussianBlur on a uint8 plane: OpenCV's bit-exact fixed-point path, 8-bit taps kern[ksize]
+ *                    (sum 256, host: getGaussianKernelFixedPoint_ED), one rounding at the end, BORDER_REFLECT_101;
+ *                    out of place                                                              agpr.py:245 via :286-287
  * bgr: [npx][3] interleaved (cv.imread layout); planes: [npx].
  */
 int gpsr_bgr2gray(const uint8_t* bgr, uint8_t* gray, size_t npx, void* stream);
@@ -301,6 +304,7 @@ int gpsr_bgr2ycrcb(const uint8_t* bgr, uint8_t* Y, uint8_t* Cr, uint8_t* Cb, siz
 int gpsr_ycrcb2bgr(const uint8_t* Y, const uint8_t* Cr, const uint8_t* Cb, uint8_t* bgr, size_t npx, void* stream);
 int gpsr_resample_u8(const uint8_t* src, int Hs, int Ws, uint8_t* dst, int Hd, int Wd,
                      const int32_t* xi, const int32_t* xa, const int32_t* yi, const int32_t* ya, void* stream);
+int gpsr_sepfilter_u8(const uint8_t* src, int H, int W, uint8_t* dst, const int32_t* kern, int ksize, void* stream);
 
 /*
  * Evaluator metrics (evaluation.py:83-98): two uint8 grey images [H][W], cropped by `crop`

@@ -10,8 +10,9 @@ Restates agpr.py of the reference:
   upscale                   agpr.py:148-158 (YCrCb: GP on Y, bicubic Cr/Cb)
   active_sampling           agpr.py:120-137, 211-222 (training-set selection; numpy is the reference's own library
                             here, so this part runs the same numpy calls on the same values: pinned by construction)
-The fit is pinned by the reference's checkpoints (tests/test_oracle.py); the
-image part goes through the unpinned OpenCV restatement (oracle/cvops.py).
+The fit is pinned by the reference's checkpoints (tests/test_oracle.py); inference, back-projection, downscale and
+the YCrCb / uint8 stages are pinned by the reference's own *_AGPR2.png outputs, which those checkpoints reproduce
+(tests/test_refpin.py: 99.99 % of the pixels at x2).
 """
 import numpy as np
 import torch
@@ -31,6 +32,14 @@ def fit(train_x, train_y, iters=100, lr=0.1):
 
 
 def downscale(image, global_srf):
+    """agpr.py:244-246.  float images (the back-projection loop, the training set): float64 paths; uint8 images of
+    any channel count (agpr.py:286-287 hands it the uint8 BGR HR image): OpenCV's uint8 paths, channel by channel."""
+    if image.dtype == np.uint8:
+        b = cvops.gaussian_blur_u8(image, 3, 1)
+        size = (image.shape[1] // global_srf, image.shape[0] // global_srf)
+        if b.ndim == 2:
+            return cvops.resize_cubic(b, dsize=size)
+        return np.stack([cvops.resize_cubic(np.ascontiguousarray(b[..., c]), dsize=size) for c in range(b.shape[2])], -1)
     image = cvops.gaussian_blur(image, 3, 1)
     return cvops.resize_cubic(image, dsize=(image.shape[1] // global_srf, image.shape[0] // global_srf))
 

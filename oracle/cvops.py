@@ -175,6 +175,42 @@ def gaussian_kernel(ksize, sigma):
     return k * (1.0 / k.sum())
 
 
+def gaussian_kernel_u8(ksize, sigma):
+    """The 8-bit fixed-point Gaussian taps cv.GaussianBlur uses on CV_8U images (smooth.dispatch.cpp,
+    getGaussianKernelFixedPoint_ED with 8 fraction bits): the left half of the float kernel times 256, rounded (ties
+    to even) with the rounding error carried to the next tap, mirrored; the centre tap takes what is left of 256."""
+    k = gaussian_kernel(ksize, sigma)
+    out = [0] * ksize
+    err = 0.0
+    for i in range(ksize // 2):
+        adj = float(k[i]) * 256.0 + err
+        v = cv_round(adj)
+        err = adj - v
+        out[i] = out[ksize - 1 - i] = v
+    out[ksize // 2] = 256 - sum(out)
+    return np.array(out, dtype=np.int64)
+
+
+def gaussian_blur_u8(img, ksize, sigma):
+    """cv.GaussianBlur on a uint8 image [H,W] or [H,W,C] (agpr.py:245 applied to the uint8 BGR image, agpr.py:286-287):
+    OpenCV's bit-exact fixed-point path -- horizontal pass exact in 8.8 fixed point, vertical pass in 16.16, one
+    rounding (half up) at the end; BORDER_REFLECT_101; channels independently.  Pinned by the reference's AGPR
+    outputs (tests/test_refpin.py)."""
+    if img.ndim == 3:
+        return np.stack([gaussian_blur_u8(np.ascontiguousarray(img[..., c]), ksize, sigma) for c in range(img.shape[2])], -1)
+    assert img.dtype == np.uint8
+    k = gaussian_kernel_u8(ksize, sigma)
+    H, W = img.shape
+    r = ksize // 2
+    ri = [_reflect101(i, H) for i in range(-r, H + r)]
+    ci = [_reflect101(i, W) for i in range(-r, W + r)]
+    p = img.astype(np.int64)[:, ci]
+    h = sum(int(k[a]) * p[:, a:a + W] for a in range(ksize))
+    q = h[ri]
+    v = sum(int(k[a]) * q[a:a + H] for a in range(ksize))
+    return ((v + (1 << 15)) >> 16).astype(np.uint8)
+
+
 def gaussian_blur(img, ksize, sigma):
     """Separable symmetric filter, BORDER_REFLECT_101, rows then columns."""
     k = gaussian_kernel(ksize, sigma)

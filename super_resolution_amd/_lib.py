@@ -70,6 +70,7 @@ SIGNATURES = {
     "gpsr_active_sample_workspace_bytes": (c_size_t, [c_int]),
     "gpsr_active_sample": (c_int, [c_void_p, c_int, c_int, c_int, c_int, ctypes.c_double, ctypes.c_double,
                                    ctypes.c_double, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "gpsr_sepfilter_u8": (c_int, [c_void_p, c_int, c_int, c_void_p, c_void_p, c_int, c_void_p]),
     "gpsr_metrics_workspace_bytes": (c_size_t, [c_int, c_int, c_int]),
     "gpsr_metrics": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t, c_void_p]),
 }

@@ -79,6 +79,16 @@ def downscale_device(image):
 
 
 def downscale(image: np.ndarray) -> np.ndarray:
+    """agpr.py:244-246.  uint8 images of any channel count (agpr.py:286-287 hands it the uint8 BGR HR image) take
+    OpenCV's uint8 paths channel by channel (fixed-point blur, fixed-point bicubic), float images the float64 ones."""
+    image = np.asarray(image)
+    if image.dtype == np.uint8:
+        dev = _device()
+        size = (image.shape[1] // SRF, image.shape[0] // SRF)
+        planes = [image] if image.ndim == 2 else [image[..., c] for c in range(image.shape[2])]
+        out = [imgproc.resize_cubic_u8_dev(imgproc.gaussian_blur_u8_dev(torch.as_tensor(np.ascontiguousarray(p)).to(dev), 3, 1),
+                                           dsize=size).cpu().numpy() for p in planes]
+        return out[0] if image.ndim == 2 else np.stack(out, -1)
     return downscale_device(_to_dev(image)).cpu().numpy()
 
 

@@ -994,6 +994,15 @@ extern "C" int gpsr_resample_u8(const uint8_t* src, int Hs, int Ws, uint8_t* dst
   return 0;
 }
 
+extern "C" int gpsr_sepfilter_u8(const uint8_t* src, int H, int W, uint8_t* dst, const int32_t* kern, int ksize,
+                                 void* stream) {
+  if (!src || !dst || !kern || src == dst) return arg_fail("sepfilter_u8: null pointer or in-place call");
+  if (H < 1 || W < 1 || ksize < 1 || ksize > 7 || ksize % 2 == 0) return arg_fail("sepfilter_u8: odd ksize <= 7");
+  hipLaunchKernelGGL(k_sepfilter_u8, GRID1D((size_t)H * W), src, H, W, dst, kern, ksize);
+  CHECK_LAUNCH("k_sepfilter_u8");
+  return 0;
+}
+
 static size_t metrics_parts(int H, int W, int crop) {
   const size_t Hc = (size_t)(H - 2 * crop), Wc = (size_t)(W - 2 * crop);
   return (Hc * Wc + MET_THREADS - 1) / MET_THREADS;

@@ -2185,6 +2185,24 @@ __global__ void k_resample_u8(const uint8_t* __restrict__ src, int Ws, uint8_t* 
   dst[idx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
 }
 
+// cv.GaussianBlur on a CV_8U plane (agpr.py:245 on the uint8 HR image, agpr.py:286-287): OpenCV's bit-exact fixed-point
+// path -- 8-bit taps (host: getGaussianKernelFixedPoint_ED, sum 256), horizontal pass exact in 8.8, vertical in 16.16,
+// one rounding (half up) at the end, BORDER_REFLECT_101.  Integer arithmetic: any evaluation order gives the same bits.
+__global__ void k_sepfilter_u8(const uint8_t* __restrict__ src, int H, int W, uint8_t* __restrict__ dst,
+                               const int32_t* __restrict__ kern, int ksize) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= (size_t)H * W) return;
+  const int r = (int)(idx / W), c = (int)(idx % W), rad = ksize / 2;
+  int v = 0;
+  for (int a = 0; a < ksize; ++a) {
+    const uint8_t* row = src + (size_t)reflect101(r + a - rad, H) * W;
+    int h = 0;
+    for (int b = 0; b < ksize; ++b) h += kern[b] * (int)row[reflect101(c + b - rad, W)];
+    v += kern[a] * h;
+  }
+  dst[idx] = (uint8_t)((v + (1 << 15)) >> 16);
+}
+
 // ------------------------------------------------ PSNR / SSIM (evaluation.py:83-98, skimage.metrics restated)
 // Two uint8 grey images, cropped by `crop` px on every side (Evaluator.preprocess_image).  PSNR needs the sum of
 // squared errors: integers, exact in 64 bits whatever the order.  SSIM = mean over all 7x7 windows that lie inside

@@ -107,6 +107,26 @@ def gaussian_blur(img, ksize, sigma):
     return ops.sepfilter_sym(img, k)
 
 
+def gaussian_kernel_u8(ksize, sigma):
+    """The 8-bit fixed-point taps of cv.GaussianBlur on CV_8U (getGaussianKernelFixedPoint_ED, 8 fraction bits): left
+    half = float taps * 256 rounded with the error carried on, mirrored, centre = 256 - the rest."""
+    k = gaussian_kernel(ksize, sigma)
+    out = [0] * ksize
+    err = 0.0
+    for i in range(ksize // 2):
+        adj = float(k[i]) * 256.0 + err
+        v = cv_round(adj)
+        err = adj - v
+        out[i] = out[ksize - 1 - i] = v
+    out[ksize // 2] = 256 - sum(out)
+    return np.array(out, dtype=np.int32)
+
+
+def gaussian_blur_u8_dev(img, ksize, sigma):
+    """cv.GaussianBlur on a uint8 device plane (OpenCV's fixed-point path)."""
+    return ops.sepfilter_u8(img, torch.as_tensor(gaussian_kernel_u8(ksize, sigma)).to(img.device))
+
+
 def filter2d_3x3(img, kern):
     k = torch.as_tensor(np.ascontiguousarray(np.asarray(kern, dtype=np.float64).reshape(9))).to(img.device)
     return ops.filter3x3(img, k)

@@ -342,6 +342,16 @@ def resample_u8(img, Hd, Wd, xi, xa, yi, ya):
     return out
 
 
+def sepfilter_u8(img, kern):
+    """uint8 device plane [H,W], int32 fixed-point taps (sum 256) -> blurred uint8 plane (gpsr_sepfilter_u8)."""
+    lib = _lib.load()
+    H, W = img.shape
+    out = torch.empty_like(img)
+    _lib.check(lib.gpsr_sepfilter_u8(_p(img, torch.uint8), H, W, _p(out), _p(kern, torch.int32), kern.numel(), _stream()),
+               "gpsr_sepfilter_u8")
+    return out
+
+
 def metrics(a, b, crop):
     """Two [H,W] uint8 device images -> device float64 [3] = (PSNR dB, SSIM, MSE) after cropping (gpsr_metrics)."""
     lib = _lib.load()

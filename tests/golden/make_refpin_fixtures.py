@@ -24,6 +24,8 @@ one combination that reproduces the file, the others are far off (20-70 % identi
         YUV, BILINEAR patch interpolation (image_patches.py:67-70) and EVERY PATCH FROM THE INITIAL HYPER-PARAMETERS:
         an earlier state of the reference in which the kernel was not yet a shared singleton -- exactly this
         repo's warm_start="independent".  (x3 linear: chain / AVERAGE, like matern12.)  x4 runs x2 twice (gprsr.py:94-96).
+  Set14/image_SRF_{2,3}/img_XXX_SRF_s_{HR,AGPR2}.png -> refpin/agpr_x{s}_{hr,ref}_XXX.png
+        AGPR (agpr.py:284-289) with the committed BSD100 checkpoints: LR = downscale(uint8 BGR HR), YCrCb mode.
 """
 import os
 import sys
@@ -72,4 +74,9 @@ for tag in ("matern32", "linear"):
 for i in (4, 5, 6, 8):   # more (small) images of the x3 Matern-3/2 loop over Set14: independent starts, any order
     save_rgb(f"{REF}/image_SRF_3/img_{i:03d}_SRF_3_LR.png", f"x3_lr_{i:03d}.png")
     save_rgb(f"{REF}/image_SRF_3/img_{i:03d}_SRF_3_GPR_matern32.png", f"x3_ref_matern32_yuv_{i:03d}.png")
+# AGPR: the outputs the reference wrote with the checkpoints it committed (agpr.py:284-289: HR -> downscale -> upscale ->
+# *_AGPR2.png; DATASET = BSD100).  The checkpoints are fixtures already (tests/golden/agpr_BSD100_SRF_{2,3}.npz).
+for s_, i in ((2, 6), (2, 4), (3, 6)):
+    save_rgb(f"{REF}/image_SRF_{s_}/img_{i:03d}_SRF_{s_}_HR.png", f"agpr_x{s_}_hr_{i:03d}.png")
+    save_rgb(f"{REF}/image_SRF_{s_}/img_{i:03d}_SRF_{s_}_AGPR2.png", f"agpr_x{s_}_ref_{i:03d}.png")
 print("ok", sorted(os.listdir(OUT)))

@@ -164,3 +164,37 @@ def test_active_sampling_rejects_bad_sizes():
         ops.active_sample(data, 5, len(data) + 1, 1.0, 0.2, 0.8)
     with pytest.raises(_lib.GpsrError):
         ops.active_sample(data, 5, 5, 0.0, 0.2, 0.8)          # bandwidth
+
+
+@pytest.mark.parametrize("s,i,min_ident", [(2, 6, 0.9998), (2, 4, 0.9998), (3, 6, 0.995)])
+def test_agpr_drop_in_reproduces_the_references_outputs_from_its_checkpoints(tmp_path, golden_dir, s, i, min_ident):
+    """HIP path vs a REFERENCE golden: agpr.py:284-289 through the drop-in (downscale of the uint8 BGR HR image on the GPU,
+    AGPRSuperResolution(use_existing_model=True) on the reference's committed checkpoint, upscale in YCrCb mode)
+    against the *_AGPR2.png the reference committed.  Same bars as the oracle's test (tests/test_refpin.py)."""
+    from PIL import Image
+    from super_resolution_amd import agpr
+    _write_checkpoint(str(tmp_path), golden_dir, f"BSD100/SRF_{s}")
+    old = (agpr.BASE_DIR, agpr.SRF, agpr.DATASET, agpr.COLOR_SPACE)
+    agpr.BASE_DIR, agpr.SRF, agpr.DATASET, agpr.COLOR_SPACE = str(tmp_path), s, agpr.TrainingDataset.BSD100, agpr.ColorSpace.YCRCB
+    try:
+        load = lambda n: np.ascontiguousarray(np.array(Image.open(os.path.join(golden_dir, "refpin", n)))[..., ::-1])
+        hr, ref = load(f"agpr_x{s}_hr_{i:03d}.png"), load(f"agpr_x{s}_ref_{i:03d}.png")
+        lr = agpr.downscale(hr)
+        assert np.array_equal(lr, oagpr.downscale(hr, s))             # uint8 blur + uint8 bicubic: bit for bit
+        out = agpr.AGPRSuperResolution(s, use_existing_model=True).upscale(lr)
+    finally:
+        agpr.BASE_DIR, agpr.SRF, agpr.DATASET, agpr.COLOR_SPACE = old
+    d = np.abs(out.astype(int) - ref.astype(int))
+    ident = float((d == 0).mean())
+    print(f"AGPR x{s} img_{i:03d} vs the reference's AGPR2 PNG: {100 * ident:.4f} % identical, max |diff| {d.max()}")
+    assert out.shape == ref.shape and ident >= min_ident and d.max() <= 3
+
+
+def test_sepfilter_u8_bit_exact():
+    from super_resolution_amd import imgproc
+    rng = np.random.default_rng(3)
+    for (H, W), ks, sg in (((37, 53), 3, 1), ((5, 4), 5, 0), ((64, 31), 7, 1.5), ((1, 9), 3, 1)):
+        img = rng.integers(0, 256, (H, W), dtype=np.uint8)
+        got = imgproc.gaussian_blur_u8_dev(torch.as_tensor(img).cuda(), ks, sg).cpu().numpy()
+        from oracle import cvops
+        assert np.array_equal(got, cvops.gaussian_blur_u8(img, ks, sg)), (H, W, ks)

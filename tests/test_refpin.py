@@ -122,3 +122,31 @@ def test_oracle_independent_bilinear_reproduces_the_references_x4_matern32_colou
     ident, maxd = _stats(out, _bgr(_load(golden_dir, "x4_ref_matern32_yuv_001.png")))
     print(f"oracle independent / BILINEAR vs the reference's x4 matern32 PNG: {100 * ident:.4f} % identical, max |diff| {maxd}")
     assert ident >= 0.999 and maxd <= 2
+
+
+# ---------------------------------------------------------------- AGPR: the reference's *_AGPR2.png outputs
+@pytest.mark.parametrize("s,i,min_ident", [(2, 6, 0.9998), (2, 4, 0.9998), (3, 6, 0.995)])
+def test_oracle_agpr_reproduces_the_references_outputs_from_its_checkpoints(golden_dir, s, i, min_ident):
+    """agpr.py:284-289 restated end to end: uint8 BGR HR image -> downscale (cv.GaussianBlur 3x3 sigma 1 and INTER_CUBIC
+    on uint8: OpenCV's fixed-point paths) -> upscale (BGR2YCrCb, Y/255, float64 bicubic, the linear-kernel GP mean of
+    every 7x7 window with the reference's COMMITTED checkpoint, iterative back-projection, clip, truncating cast,
+    uint8 bicubic Cr / Cb, YCrCb2BGR) against the *_AGPR2.png the reference committed.  Measured: x2 99.995 % / 99.998 %
+    identical (max 2 / 1: the reference predicts in float32, a handful of truncations fall the other way), x3 99.74 %
+    (max 2: the x3 uint8 chroma resize, see the colour pins above).  This pins AGPR inference, the back-projection
+    loop, GaussianBlur 3x3 (float64 and uint8), filter2D and the YCrCb pair -- no GPyTorch needed."""
+    from oracle import agpr as oagpr
+    f = np.load(os.path.join(golden_dir, f"agpr_BSD100_SRF_{s}.npz"))
+    h = ogp.Hypers(*f["raw"].astype(np.float32))
+    hr = _bgr(_load(golden_dir, f"agpr_x{s}_hr_{i:03d}.png"))
+    lr = oagpr.downscale(hr, s)
+    assert lr.dtype == np.uint8 and lr.shape == (hr.shape[0] // s, hr.shape[1] // s, 3)
+    out = oagpr.upscale(lr, s, h, f["train_x"], f["train_y"], grayscale=False, global_srf=s)
+    ident, maxd = _stats(out, _bgr(_load(golden_dir, f"agpr_x{s}_ref_{i:03d}.png")))
+    print(f"oracle AGPR x{s} img_{i:03d} vs the reference's AGPR2 PNG: {100 * ident:.4f} % identical, max |diff| {maxd}")
+    assert ident >= min_ident and maxd <= 3
+
+
+def test_uint8_gaussian_taps_are_opencvs_fixed_point_ones():
+    assert list(cvops.gaussian_kernel_u8(3, 1)) == [70, 116, 70]        # 0.274, 0.452, 0.274 at 8 fraction bits, sum 256
+    assert list(cvops.gaussian_kernel_u8(5, 0)) == [16, 64, 96, 64, 16]
+    assert sum(cvops.gaussian_kernel_u8(7, 1.5)) == 256
