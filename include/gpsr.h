@@ -288,10 +288,9 @@ int gpsr_axpy(const double* a, const double* b, double alpha, double* dst, size_
  *   gpsr_bgr2yuv     cv.cvtColor(COLOR_BGR2YUV)  + cv.split -> planes Y, U, V      gprsr.py:57-58
  *   gpsr_yuv2bgr     cv.merge + cv.cvtColor(COLOR_YUV2BGR)                         gprsr.py:62-63
  *   gpsr_bgr2ycrcb / gpsr_ycrcb2bgr   the same for YCrCb                           agpr.py:150-156
- *   gpsr_resample_u8 cv.resize(INTER_CUBIC) on a uint8 plane: 11-bit fixed-point taps (xa, ya = cvRound(coef*2048),
- *                    host tables [n][4] as for gpsr_resample), integer horizontal pass; vertical pass as OpenCV's
- *                    AVX2 loop: float32 fused multiply-adds, ties to even, in column steps of 16, the tail columns
- *                    (x + 2^21) >> 22; saturated (pinned by the reference's colour outputs)   gprsr.py:60-61, agpr.py:152-153
+ *   gpsr_resample_u8 cv.resize(INTER_CUBIC) on a uint8 plane as the reference's (IPP-backed) OpenCV ran it: float32
+ *                    taps xw, yw (host tables [n][4], not quantised), float32 passes, ties to even -- fitted to and
+ *                    pinned by the reference's own uint8 planes (oracle/cvops.py)    gprsr.py:60-61, agpr.py:152-153, 246
  *   gpsr_sepfilter_u8 cv.GaussianBlur on a uint8 plane: OpenCV's bit-exact fixed-point path, 8-bit taps kern[ksize]
  *                    (sum 256, host: getGaussianKernelFixedPoint_ED), one rounding at the end, BORDER_REFLECT_101;
  *                    out of place                                                              agpr.py:245 via :286-287
@@ -303,7 +302,7 @@ int gpsr_yuv2bgr(const uint8_t* Y, const uint8_t* U, const uint8_t* V, uint8_t* 
 int gpsr_bgr2ycrcb(const uint8_t* bgr, uint8_t* Y, uint8_t* Cr, uint8_t* Cb, size_t npx, void* stream);
 int gpsr_ycrcb2bgr(const uint8_t* Y, const uint8_t* Cr, const uint8_t* Cb, uint8_t* bgr, size_t npx, void* stream);
 int gpsr_resample_u8(const uint8_t* src, int Hs, int Ws, uint8_t* dst, int Hd, int Wd,
-                     const int32_t* xi, const int32_t* xa, const int32_t* yi, const int32_t* ya, void* stream);
+                     const int32_t* xi, const float* xw, const int32_t* yi, const float* yw, void* stream);
 int gpsr_sepfilter_u8(const uint8_t* src, int H, int W, uint8_t* dst, const int32_t* kern, int ksize, void* stream);
 
 /*

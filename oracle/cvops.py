@@ -58,10 +58,56 @@ def _cubic_tables(n_dst, n_src, inv_scale):
     return idx, cf
 
 
+def _cubic_tables_u8(n_dst, n_src):
+    """Taps of the uint8 path: position and the A = -0.75 polynomials in float64, the four weights rounded to float32."""
+    A = -0.75
+    scale = n_src / n_dst
+    idx = np.zeros((n_dst, 4), dtype=np.int64)
+    cf = np.zeros((n_dst, 4), dtype=np.float32)
+    for d in range(n_dst):
+        f = (d + 0.5) * scale - 0.5
+        sx = int(np.floor(f))
+        x = f - sx
+        c0 = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A
+        c1 = ((A + 2) * x - (A + 3)) * x * x + 1
+        c2 = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1
+        cf[d] = [c0, c1, c2, 1 - c0 - c1 - c2]
+        for k in range(4):
+            idx[d, k] = min(max(sx - 1 + k, 0), n_src - 1)
+    return idx, cf
+
+
+def _fma32(a, b, c):
+    """float32 fused multiply-add: the product of two float32 is exact in float64, one rounding to float32."""
+    return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+
+
+def _resize_cubic_u8(img, Wd, Hd):
+    """cv.resize(INTER_CUBIC) on a uint8 plane AS THE REFERENCE'S OpenCV RAN IT.  Not resize.cpp's own fixed-point code
+    (11-bit taps, (x + 2^21) >> 22): the opencv-python wheels route uint8 bicubic through IPP, whose arithmetic is
+    closed source.  The model below was fitted to the images the reference committed, pixel by pixel and without any
+    GP fit (tests/test_refpin.py): float32 taps (not quantised), float32 passes, horizontal then vertical, each
+    pass (t0 w0 + t1 w1) + (t2 w2 + t3 w3) with the first product of a pair fused, ties to even.  It reproduces EVERY
+    pixel of the reference's x2 and x4 chroma planes and of its uint8 downscales (498 -> 249 -> 124 columns, a
+    non-dyadic ratio) and 99.89 % of its x3 chroma planes; resize.cpp's integer code: 4-5 pixels per image off at
+    x2 / x4, 98.2 % on the 249 -> 124 downscale, 99.06 % at x3."""
+    H, W = img.shape
+    xi, xc = _cubic_tables_u8(Wd, W)
+    yi, yc = _cubic_tables_u8(Hd, H)
+    src = img.astype(np.float32)
+    t = [src[:, xi[:, k]] for k in range(4)]
+    w = [xc[None, :, k] for k in range(4)]
+    hbuf = _fma32(t[0], w[0], t[1] * w[1]) + _fma32(t[2], w[2], t[3] * w[3])
+    t = [hbuf[yi[:, k]] for k in range(4)]
+    w = [yc[:, k, None] for k in range(4)]
+    out = _fma32(t[0], w[0], t[1] * w[1]) + _fma32(t[2], w[2], t[3] * w[3])
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)
+
+
 def resize_cubic(img, fx=None, fy=None, dsize=None):
     """cv.resize(INTER_CUBIC).  float64 images: float32 coefficients, float64
-    accumulation, horizontal pass then vertical pass.  uint8 images: 11-bit
-    fixed-point coefficients, integer horizontal pass, float32 vertical pass (below), saturate."""
+    accumulation, horizontal pass then vertical pass.  uint8 images: float32 model of the
+    IPP-backed path the reference ran (_resize_cubic_u8)."""
     H, W = img.shape
     if dsize is None:
         Wd, Hd = cv_round(W * fx), cv_round(H * fy)
@@ -72,35 +118,7 @@ def resize_cubic(img, fx=None, fy=None, dsize=None):
     xi, xc = _cubic_tables(Wd, W, isx)
     yi, yc = _cubic_tables(Hd, H, isy)
     if img.dtype == np.uint8:
-        xa = np.array([[cv_round(float(c) * 2048) for c in row] for row in xc], dtype=np.int64)
-        ya = np.array([[cv_round(float(c) * 2048) for c in row] for row in yc], dtype=np.int64)
-        src = img.astype(np.int64)
-        hbuf = np.zeros((H, Wd), dtype=np.int64)
-        for k in range(4):
-            hbuf += src[:, xi[:, k]] * xa[None, :, k]
-        # Vertical pass as resize.cpp runs it on x86: VResizeCubicVec_32s8u covers the columns in steps of 16
-        # (AVX2) in float32, fma(s0,b0, fma(s1,b1, fma(s2,b2, s3*b3))) with b = beta / 2^22, rounded half to EVEN; the
-        # tail columns take the integer form (x + 2^21) >> 22 (half UP).  They differ on exact ties only.  Pinned:
-        # with the float form the chroma of the reference's own x2 / x4 colour outputs is reproduced on every
-        # pixel, with the integer form on all but a handful, with unfused multiply-adds or 32-column steps on all
-        # but one (tests/test_refpin.py): an AVX2 + FMA3 build.
-        out = np.zeros((Hd, Wd), dtype=np.int64)
-        nvec = (Wd // 16) * 16
-        scale = np.float32(1.0) / np.float32(2048 * 2048)
-        for r in range(Hd):
-            S = [hbuf[yi[r, k]] for k in range(4)]
-            acc = np.zeros(Wd, dtype=np.int64)
-            for k in range(4):
-                acc += S[k] * ya[r, k]
-            row = (acc + (1 << 21)) >> 22
-            b = [np.float32(ya[r, k]) * scale for k in range(4)]
-            Sf = [s_[:nvec].astype(np.float32) for s_ in S]
-            f = Sf[3] * b[3]
-            for k in (2, 1, 0):   # fused multiply-add: the float32 product is exact in float64, one rounding to float32
-                f = (Sf[k].astype(np.float64) * np.float64(b[k]) + f.astype(np.float64)).astype(np.float32)
-            row[:nvec] = np.rint(f).astype(np.int64)
-            out[r] = row
-        return np.clip(out, 0, 255).astype(np.uint8)
+        return _resize_cubic_u8(img, Wd, Hd)
     src = img.astype(np.float64)
     xcd = xc.astype(np.float64)
     ycd = yc.astype(np.float64)

@@ -986,10 +986,10 @@ extern "C" int gpsr_ycrcb2bgr(const uint8_t* Y, const uint8_t* Cr, const uint8_t
 }
 
 extern "C" int gpsr_resample_u8(const uint8_t* src, int Hs, int Ws, uint8_t* dst, int Hd, int Wd, const int32_t* xi,
-                                const int32_t* xa, const int32_t* yi, const int32_t* ya, void* stream) {
-  if (!src || !dst || !xi || !xa || !yi || !ya) return arg_fail("null pointer");
+                                const float* xw, const int32_t* yi, const float* yw, void* stream) {
+  if (!src || !dst || !xi || !xw || !yi || !yw) return arg_fail("null pointer");
   if (Hs < 1 || Ws < 1 || Hd < 1 || Wd < 1) return arg_fail("resample_u8 shape");
-  hipLaunchKernelGGL(k_resample_u8, GRID1D((size_t)Hd * Wd), src, Ws, dst, Hd, Wd, xi, xa, yi, ya);
+  hipLaunchKernelGGL(k_resample_u8, GRID1D((size_t)Hd * Wd), src, Ws, dst, Hd, Wd, xi, xw, yi, yw);
   CHECK_LAUNCH("k_resample_u8");
   return 0;
 }

@@ -2149,40 +2149,28 @@ __global__ void k_ycc2bgr(const uint8_t* __restrict__ Y, const uint8_t* __restri
   bgr[3 * i + 2] = sat_u8(y + descale_i(cr * c0, 14));
 }
 
-// cv.resize INTER_CUBIC on CV_8U (gprsr.py:60-61, agpr.py:152-153: the chroma planes): 11-bit fixed-point taps
-// (host tables, cvRound(coef * 2048)), integer horizontal pass.  Vertical pass as OpenCV's resize.cpp runs it: the
-// columns its SIMD loop covers (VResizeCubicVec_32s8u, 16 columns per step) are evaluated in float32 --
-// fma(s0,b0, fma(s1,b1, fma(s2,b2, s3*b3))), b = beta / 2^22, rounded half to EVEN -- and only the tail columns take the
-// integer form (x + 2^21) >> 22, which rounds half UP.  The two differ exactly on ties (a handful of pixels per
-// image at x2): with the float form the reference's own colour outputs are reproduced pixel for pixel.
-#define RESIZE_U8_VLANES 16
+// cv.resize INTER_CUBIC on a CV_8U plane (gprsr.py:60-61, agpr.py:152-153, 246: chroma planes, the uint8 downscale) as the
+// reference's OpenCV ran it: float32 taps (host tables, not quantised), float32 passes, horizontal then vertical, each
+// (t0 w0 + t1 w1) + (t2 w2 + t3 w3) with the first product of a pair fused, ties to even -- the arithmetic that
+// reproduces the reference's own uint8 planes pixel for pixel (oracle/cvops.py::_resize_cubic_u8 has the evidence;
+// resize.cpp's 11-bit fixed-point code does not: the opencv-python wheels route this call through IPP).
 __global__ void k_resample_u8(const uint8_t* __restrict__ src, int Ws, uint8_t* __restrict__ dst, int Hd, int Wd,
-                              const int32_t* __restrict__ xi, const int32_t* __restrict__ xa,
-                              const int32_t* __restrict__ yi, const int32_t* __restrict__ ya) {
+                              const int32_t* __restrict__ xi, const float* __restrict__ xw,
+                              const int32_t* __restrict__ yi, const float* __restrict__ yw) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (size_t)Hd * Wd) return;
   const int r = (int)(idx / Wd), c = (int)(idx % Wd);
-  int h[4];
+  const float w0 = xw[4 * c], w1 = xw[4 * c + 1], w2 = xw[4 * c + 2], w3 = xw[4 * c + 3];
+  float h[4];
   for (int k = 0; k < 4; ++k) {
     const uint8_t* row = src + (size_t)yi[4 * r + k] * Ws;
-    h[k] = 0;
-    for (int j = 0; j < 4; ++j) h[k] += (int)row[xi[4 * c + j]] * xa[4 * c + j];
+    const float t0 = (float)row[xi[4 * c]], t1 = (float)row[xi[4 * c + 1]], t2 = (float)row[xi[4 * c + 2]],
+                t3 = (float)row[xi[4 * c + 3]];
+    h[k] = __builtin_fmaf(t0, w0, t1 * w1) + __builtin_fmaf(t2, w2, t3 * w3);   // nothing else contracts (-ffp-contract=off)
   }
-  long long v;
-  if (c < (Wd / RESIZE_U8_VLANES) * RESIZE_U8_VLANES) {
-    const float scale = 1.f / (2048.f * 2048.f);
-    const float b0 = (float)ya[4 * r] * scale, b1 = (float)ya[4 * r + 1] * scale, b2 = (float)ya[4 * r + 2] * scale,
-                b3 = (float)ya[4 * r + 3] * scale;
-    // v_muladd is a fused multiply-add on the AVX2 / FMA3 builds OpenCV ships: decided by one pixel of the
-    // reference's x4 output (tests/test_refpin.py), which the unfused form gets wrong
-    const float f = __builtin_fmaf((float)h[0], b0, __builtin_fmaf((float)h[1], b1, __builtin_fmaf((float)h[2], b2, (float)h[3] * b3)));
-    v = (long long)rintf(f);
-  } else {
-    long long acc = 0;
-    for (int k = 0; k < 4; ++k) acc += (long long)h[k] * ya[4 * r + k];
-    v = (acc + (1ll << 21)) >> 22;
-  }
-  dst[idx] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  const float f = __builtin_fmaf(h[0], yw[4 * r], h[1] * yw[4 * r + 1]) + __builtin_fmaf(h[2], yw[4 * r + 2], h[3] * yw[4 * r + 3]);
+  const float v = rintf(f);
+  dst[idx] = (uint8_t)(v < 0.f ? 0.f : (v > 255.f ? 255.f : v));
 }
 
 // cv.GaussianBlur on a CV_8U plane (agpr.py:245 on the uint8 HR image, agpr.py:286-287): OpenCV's bit-exact fixed-point

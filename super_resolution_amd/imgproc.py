@@ -133,20 +133,35 @@ def filter2d_3x3(img, kern):
 
 
 # ---------------------------------------------------------------- uint8 stages on the device
+@lru_cache(maxsize=64)
+def _axis_tables_u8(n_dst, n_src):
+    """Taps of the uint8 bicubic path (the float32 model of the IPP-backed cv.resize the reference ran, see
+    k_resample_u8): position and the A = -0.75 polynomials in float64, the four weights rounded to float32."""
+    A = -0.75
+    f = (np.arange(n_dst, dtype=np.float64) + 0.5) * (n_src / n_dst) - 0.5
+    sx = np.floor(f)
+    x = f - sx
+    c0 = ((A * (x + 1) - 5 * A) * (x + 1) + 8 * A) * (x + 1) - 4 * A
+    c1 = ((A + 2) * x - (A + 3)) * x * x + 1
+    c2 = ((A + 2) * (1 - x) - (A + 3)) * (1 - x) * (1 - x) + 1
+    w = np.stack([c0, c1, c2, 1 - c0 - c1 - c2], axis=1).astype(np.float32)
+    idx = np.clip(sx.astype(np.int64)[:, None] + np.arange(-1, 3)[None, :], 0, n_src - 1).astype(np.int32)
+    return np.ascontiguousarray(idx), np.ascontiguousarray(w)
+
+
+def _u8_dsize(H, W, fx, fy, dsize):
+    return (cv_round(W * fx), cv_round(H * fy)) if dsize is None else tuple(dsize)
+
+
 def resize_cubic_u8_dev(img, fx=None, fy=None, dsize=None):
     """cv.resize INTER_CUBIC on a uint8 device plane (the chroma planes, gprsr.py:60-61 / agpr.py:152-153)."""
     H, W = img.shape
-    if dsize is None:
-        Wd, Hd, isx, isy = cv_round(W * fx), cv_round(H * fy), fx, fy
-    else:
-        Wd, Hd = dsize
-        isx, isy = Wd / W, Hd / H
-    xi, xw = _axis_tables(Wd, W, float(isx), "cubic")
-    yi, yw = _axis_tables(Hd, H, float(isy), "cubic")
+    Wd, Hd = _u8_dsize(H, W, fx, fy, dsize)
+    xi, xw = _axis_tables_u8(Wd, W)
+    yi, yw = _axis_tables_u8(Hd, H)
     dev = img.device
-    xa = torch.as_tensor(np.rint(xw * 2048).astype(np.int32)).to(dev)
-    ya = torch.as_tensor(np.rint(yw * 2048).astype(np.int32)).to(dev)
-    return ops.resample_u8(img, Hd, Wd, torch.as_tensor(xi).to(dev), xa, torch.as_tensor(yi).to(dev), ya)
+    return ops.resample_u8(img, Hd, Wd, torch.as_tensor(xi).to(dev), torch.as_tensor(xw).to(dev),
+                           torch.as_tensor(yi).to(dev), torch.as_tensor(yw).to(dev))
 
 
 # ---------------------------------------------------------------- uint8 host code (host callers: file loops, tests)
@@ -197,27 +212,19 @@ def ycrcb2bgr(Y, Cr, Cb):
 
 
 def resize_cubic_u8(img, fx=None, fy=None, dsize=None):
-    """cv.resize INTER_CUBIC on uint8 (chroma planes): 11-bit fixed-point taps, float32 vertical pass."""
+    """cv.resize INTER_CUBIC on uint8, host form of k_resample_u8 (same float32 arithmetic, fused products included)."""
     H, W = img.shape
-    if dsize is None:
-        Wd, Hd, isx, isy = cv_round(W * fx), cv_round(H * fy), fx, fy
-    else:
-        Wd, Hd = dsize
-        isx, isy = Wd / W, Hd / H
-    xi, xw = _axis_tables(Wd, W, float(isx), "cubic")
-    yi, yw = _axis_tables(Hd, H, float(isy), "cubic")
-    xa = np.rint(xw * 2048).astype(np.int64)
-    ya = np.rint(yw * 2048).astype(np.int64)
-    src = img.astype(np.int64)
-    hbuf = (src[:, xi] * xa[None, :, :]).sum(-1)                 # [H, Wd]
-    out = ((hbuf[yi] * ya[:, :, None]).sum(1) + (1 << 21)) >> 22  # [Hd, Wd]: the tail columns of OpenCV's loop
-    # the columns OpenCV's SIMD loop covers (16 per step) are evaluated in float32 and rounded half to even
-    # (VResizeCubicVec_32s8u); same arithmetic as k_resample_u8
-    nvec = (Wd // 16) * 16
-    S = hbuf[yi][:, :, :nvec].astype(np.float32)                 # [Hd, 4, nvec]
-    b = ya.astype(np.float32) * np.float32(1.0 / (2048.0 * 2048.0))
-    f = S[:, 3] * b[:, 3, None]
-    for k in (2, 1, 0):   # fused multiply-adds (v_muladd on FMA3 builds): float32 products are exact in float64
-        f = (S[:, k].astype(np.float64) * b[:, k, None].astype(np.float64) + f.astype(np.float64)).astype(np.float32)
-    out[:, :nvec] = np.rint(f).astype(np.int64)
-    return np.clip(out, 0, 255).astype(np.uint8)
+    Wd, Hd = _u8_dsize(H, W, fx, fy, dsize)
+    xi, xw = _axis_tables_u8(Wd, W)
+    yi, yw = _axis_tables_u8(Hd, H)
+
+    def fma(a, b, c):   # float32 fused multiply-add: the float32 product is exact in float64
+        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    src = img.astype(np.float32)
+    t = [src[:, xi[:, k]] for k in range(4)]
+    w = [xw[None, :, k] for k in range(4)]
+    hbuf = fma(t[0], w[0], t[1] * w[1]) + fma(t[2], w[2], t[3] * w[3])
+    t = [hbuf[yi[:, k]] for k in range(4)]
+    w = [yw[:, k, None] for k in range(4)]
+    out = fma(t[0], w[0], t[1] * w[1]) + fma(t[2], w[2], t[3] * w[3])
+    return np.clip(np.rint(out), 0, 255).astype(np.uint8)

@@ -332,12 +332,12 @@ def ycrcb2bgr(y, cr, cb):
     return _merge3(_lib.load().gpsr_ycrcb2bgr, "gpsr_ycrcb2bgr", y, cr, cb)
 
 
-def resample_u8(img, Hd, Wd, xi, xa, yi, ya):
+def resample_u8(img, Hd, Wd, xi, xw, yi, yw):
     lib = _lib.load()
     Hs, Ws = img.shape
     out = torch.empty((Hd, Wd), dtype=torch.uint8, device=img.device)
     _lib.check(lib.gpsr_resample_u8(_p(img, torch.uint8), Hs, Ws, _p(out), Hd, Wd, _p(xi, torch.int32),
-                                    _p(xa, torch.int32), _p(yi, torch.int32), _p(ya, torch.int32), _stream()),
+                                    _p(xw, torch.float32), _p(yi, torch.int32), _p(yw, torch.float32), _stream()),
                "gpsr_resample_u8")
     return out
 

@@ -26,6 +26,8 @@ one combination that reproduces the file, the others are far off (20-70 % identi
         repo's warm_start="independent".  (x3 linear: chain / AVERAGE, like matern12.)  x4 runs x2 twice (gprsr.py:94-96).
   Set14/image_SRF_{2,3}/img_XXX_SRF_s_{HR,AGPR2}.png -> refpin/agpr_x{s}_{hr,ref}_XXX.png
         AGPR (agpr.py:284-289) with the committed BSD100 checkpoints: LR = downscale(uint8 BGR HR), YCrCb mode.
+  experiments/image{1,2}_{hr,lr,srgpr}.png -> refpin/exp_*.png   (experiment.py:9-28: two uint8 downscales, then
+        GPRSR(2).apply -- matern52, YUV, the chain running from image 1 into image 2)
 """
 import os
 import sys
@@ -79,4 +81,10 @@ for i in (4, 5, 6, 8):   # more (small) images of the x3 Matern-3/2 loop over Se
 for s_, i in ((2, 6), (2, 4), (3, 6)):
     save_rgb(f"{REF}/image_SRF_{s_}/img_{i:03d}_SRF_{s_}_HR.png", f"agpr_x{s_}_hr_{i:03d}.png")
     save_rgb(f"{REF}/image_SRF_{s_}/img_{i:03d}_SRF_{s_}_AGPR2.png", f"agpr_x{s_}_ref_{i:03d}.png")
+# experiment.py of the reference: hr = downscale(cv.imread(HR x3 file)), lr = downscale(hr) on uint8 BGR images (global
+# SRF = 2), srgpr = GPRSR(2).apply(lr) (defaults: matern52, YUV) for image 1 and then image 2 in ONE process.
+EXP = "/root/reference/experiments"
+for src, dst in (("image1_hr", "exp_hr_1"), ("image1_lr", "exp_lr_1"), ("image1_srgpr", "exp_srgpr_1"),
+                 ("image2_lr", "exp_lr_2"), ("image2_srgpr", "exp_srgpr_2")):
+    save_rgb(f"{EXP}/{src}.png", f"{dst}.png")
 print("ok", sorted(os.listdir(OUT)))

@@ -166,7 +166,7 @@ def test_active_sampling_rejects_bad_sizes():
         ops.active_sample(data, 5, 5, 0.0, 0.2, 0.8)          # bandwidth
 
 
-@pytest.mark.parametrize("s,i,min_ident", [(2, 6, 0.9998), (2, 4, 0.9998), (3, 6, 0.995)])
+@pytest.mark.parametrize("s,i,min_ident", [(2, 6, 0.99999), (2, 4, 0.9999), (3, 6, 0.999)])
 def test_agpr_drop_in_reproduces_the_references_outputs_from_its_checkpoints(tmp_path, golden_dir, s, i, min_ident):
     """HIP path vs a REFERENCE golden: agpr.py:284-289 through the drop-in (downscale of the uint8 BGR HR image on the GPU,
     AGPRSuperResolution(use_existing_model=True) on the reference's committed checkpoint, upscale in YCrCb mode)

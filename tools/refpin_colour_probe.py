@@ -36,7 +36,7 @@ for case in cases:
     noise0 = mean0 = 0
     for o in parts[4:]:
         k, v = o.split("=")
-        if k in ("ref", "lr"): continue
+        if k in ("ref", "lr", "then", "thenref"): continue
         if k == "grid": gprsr.USE_ALL_PIXELS_FOR_TRAINING = not int(v)
         if k == "lr": gprsr.LEARNING_RATE = float(v)
         if k == "stride": gprsr.STRIDE_PERCENTAGE = float(v)
@@ -87,7 +87,12 @@ for case in cases:
         report(f"{case} ({time.time() - t0:.1f}s)", got, ref)
         os.makedirs(os.path.join(ROOT, "gpurun_out", "probe"), exist_ok=True)
         np.save(os.path.join(ROOT, "gpurun_out", "probe", case.replace(":", "_").replace("/", "_") + ".npy"), got)
-        if s == 2 and os.path.exists(os.path.join(G, f"x2_ref_{tag}_yuv_002.png")) and ws == "chain":
+        nxt = next((o.split("=")[1] for o in parts[4:] if o.startswith("then=")), None)
+        if nxt:   # a second image continuing the same process (chain)
+            nref = next(o.split("=")[1] for o in parts[4:] if o.startswith("thenref="))
+            got2 = g.apply(bgr(np.array(Image.open(os.path.join(ROOT, "tests", "golden", nxt)).convert("RGB"))))
+            report(f"{case} second image", got2, bgr(np.array(Image.open(os.path.join(ROOT, "tests", "golden", nref)).convert("RGB"))))
+        elif s == 2 and os.path.exists(os.path.join(G, f"x2_ref_{tag}_yuv_002.png")) and ws == "chain":
             got2 = g.apply(bgr(load("x2_lr_002.png")))
             report(f"{case} img_002 continuing the chain ({time.time() - t0:.1f}s)", got2, bgr(load(f"x2_ref_{tag}_yuv_002.png")))
     except Exception as e:
