@@ -12,7 +12,7 @@ Restates agpr.py of the reference:
                             here, so this part runs the same numpy calls on the same values: pinned by construction)
 The fit is pinned by the reference's checkpoints (tests/test_oracle.py); inference, back-projection, downscale and
 the YCrCb / uint8 stages are pinned by the reference's own *_AGPR2.png outputs, which those checkpoints reproduce
-(tests/test_refpin.py: 99.99 % of the pixels at x2).
+(tests/test_refpin.py: every pixel of img_006 at x2).
 """
 import numpy as np
 import torch
