@@ -308,6 +308,41 @@ def main(argv=None):
                   "bar": "<= 1 grey level, 0.01 dB, 0.001 (north star)",
                   "ok": bool(maxd <= 1 and np.max(np.abs(dps)) <= 0.01 and np.max(np.abs(dss)) <= 0.001)}
 
+    # ---- the reference's own output (untimed): img_001 of Set14 x3 as the first image of a fresh process is what the
+    # reference committed as img_001_SRF_3_GPR_matern52.png (fixture refout_m52_001.png); the chained modes must reproduce it
+    # from the colour LR file through BGR2GRAY (the grey lr_*.png fixtures above were made with another grey table)
+    ref_lr, ref_png = os.path.join(ROOT, "tests", "golden", "refpin", "x3_lr_001.png"), os.path.join(GOLDEN, "refout_m52_001.png")
+    if (parity is not None and a.warm_start in ("chain", "chain_per_image") and os.path.exists(ref_lr) and os.path.exists(ref_png)):
+        from PIL import Image
+        bgr = torch.as_tensor(np.ascontiguousarray(np.array(Image.open(ref_lr).convert("RGB"))[:, :, ::-1])).to(dev)
+        g1 = GPRSR(s, kern, ColorSpace.GRAYSCALE, warm_start="chain_per_image")
+        o1 = ops.unit_to_u8(g1.apply_for_channel_device([ops.u8_to_unit(ops.bgr2gray(bgr))])[0], 255.0)
+        refimg = torch.as_tensor(np.array(Image.open(ref_png))).to(dev)
+        d1 = (o1.to(torch.int16) - refimg.to(torch.int16)).abs()
+        parity["vs_reference_png"] = {"image": "Set14/image_SRF_3/img_001_SRF_3_GPR_matern52.png (the reference's own output)",
+                                      "identical_pixel_frac": round(float((d1 == 0).float().mean()), 6),
+                                      "max_abs_diff_grey_levels": int(d1.max())}
+
+    # independent starts: the reference output this MODE reproduces is a x2 YUV / BILINEAR one (an earlier state of the
+    # reference) -- not this workload's configuration, recorded as the mode's pin (untimed, 0.1 s)
+    ref_lr, ref_png = (os.path.join(ROOT, "tests", "golden", "refpin", n) for n in ("x2_lr_001.png", "x2_ref_matern52_yuv_001.png"))
+    if parity is not None and a.warm_start == "independent" and os.path.exists(ref_lr) and os.path.exists(ref_png):
+        from PIL import Image
+        from super_resolution_amd import gprsr as _gprsr
+        from super_resolution_amd.image_patches import PatchInterpolationMode
+        old_pi, old_t = _gprsr.PATCH_INTERPOLATION, _gprsr.DO_TIMING
+        _gprsr.PATCH_INTERPOLATION, _gprsr.DO_TIMING = PatchInterpolationMode.BILINEAR, False
+        try:
+            o2 = GPRSR(2, kern, ColorSpace.YUV, warm_start="independent").apply(
+                np.ascontiguousarray(np.array(Image.open(ref_lr).convert("RGB"))[:, :, ::-1]))
+        finally:
+            _gprsr.PATCH_INTERPOLATION, _gprsr.DO_TIMING = old_pi, old_t
+        d2 = np.abs(o2.astype(int) - np.array(Image.open(ref_png).convert("RGB"))[:, :, ::-1].astype(int))
+        parity["mode_vs_reference_png"] = {
+            "image": "Set14/image_SRF_2/img_001_SRF_2_GPR_matern52.png (the reference's own output; x2, YUV, BILINEAR, "
+                     "independent starts)",
+            "identical_pixel_frac": round(float((d2 == 0).mean()), 6), "max_abs_diff_grey_levels": int(d2.max())}
+
     # roofline of the dominant kernel.  Pivots are taken two at a time: k_update2 applies both rank-112 updates of
     # a pair in one pass over A (batched 112x112x224 f64 MFMA tile products).  Algorithmic flops of one launch, per
     # GP, with R = N - 2*112 rows outside the pair: symmetric rank-224 update of the R x R trailing matrix R^2*224,
