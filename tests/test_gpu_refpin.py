@@ -8,6 +8,13 @@ equality of the PNG (the float64 oracle does reach bit equality, tests/test_refp
                                                   images in order: the warm-start chain runs through both
   x3  img_001           *_GPR_RBF.png             RBF re-initialises per patch (gprsr.py:167-172): no chain
   x3  img_001           *_GPR_matern12.png        chain, first image of a process
+  x3  img_001           *_GPR_matern52.png        the headline configuration (grey, chained)
+Colour outputs (YUV mode; settings found with tools/refpin_colour_probe.py, see tests/golden/make_refpin_fixtures.py):
+  x2  img_001           *_GPR_matern12.png        chained, AVERAGE
+  x2  img_001, img_002  *_GPR_matern52.png        warm_start="independent" + BILINEAR (an earlier state of the reference)
+  x4  img_001           *_GPR_matern32.png        the same, x4 = x2 o x2, Matern-3/2
+  x3  img_001,4,5,6,8   *_GPR_matern32.png, img_001 *_GPR_linear.png
+  experiments/image{1,2}_srgpr.png               GPRSR(2) defaults (matern52, YUV), the chain across two images
 """
 import os
 
