@@ -106,6 +106,7 @@ class BatchedGP:
         pred = torch.empty((B, Xs.shape[1]), dtype=torch.float64, device=dev)
         flags = torch.empty(B, dtype=torch.int32, device=dev)
         bc = self.chunk_size(B, n, d)
+        bc = -(-B // -(-B // bc))          # balanced chunks: 32 400 GPs under a 13 443-GP budget run as 3 x 10 800, not 13 443 + 13 443 + 5 514
         ws = self._workspace(bc, n, d, dev)
         for b0 in range(0, B, bc):
             b1 = min(B, b0 + bc)
