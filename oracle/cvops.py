@@ -7,9 +7,11 @@ filter.simd.hpp, color_rgb.simd.hpp / color_yuv.simd.hpp; skimage.metrics).
 Pinned by output images the reference itself committed (tests/golden/refpin,
 tests/test_refpin.py): bgr2gray, resize_cubic (float64), gaussian_blur(5, 0),
 resize_linear (1/2 and 1/3) are on the path of GRAYSCALE SRGPR and the chained
-oracle reproduces img_001_SRF_2_GPR_matern52_gray.png BIT FOR BIT.  Still
-"parity unpinned" (no reference-held vector): bgr2yuv / yuv2bgr / ycrcb, the
-uint8 resize_cubic, gaussian_blur(3, 1), filter2d_3x3, psnr / ssim.
+oracle reproduces img_001_SRF_2_GPR_matern52_gray.png BIT FOR BIT; bgr2yuv /
+yuv2bgr and the uint8 resize_cubic by the reference's colour outputs and uint8
+downscales (every pixel at x2, x4 and 1/2; 99.89 % at x3); bgr2ycrcb / ycrcb2bgr,
+gaussian_blur(3, 1), gaussian_blur_u8 and filter2d_3x3 by its AGPR outputs.
+Still "parity unpinned" (no reference-held vector): psnr / ssim.
 
 Call sites restated:
   resize_cubic        cv.resize(..., INTER_CUBIC)            gprsr.py:60-61,106; agpr.py:103,152-153,163,205,246

@@ -14,8 +14,10 @@ GPyTorch is NOT installed here; its semantics are restated:
   noise = softplus(raw)+1e-4, outputscale/lengthscale/variance = softplus(raw),
   loss = -log N(y | c 1, K + noise I) / n, dense Cholesky (n <= 800),
   float32 parameters promoted into float64 data, torch.optim.Adam defaults.
-The linear-kernel branch is pinned by tests/test_oracle_agpr_kat.py against
-the reference's committed checkpoints; the stationary kernels are unpinned.
+The linear-kernel branch is pinned by a known-answer test against the reference's
+committed checkpoints (tests/test_oracle.py); the stationary kernels, the initial
+values and the warm-start chain by output images the reference committed
+(tests/test_refpin.py: RBF, Matern-1/2, -3/2, -5/2, bit for bit).
 """
 import math
 
