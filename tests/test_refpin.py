@@ -85,8 +85,17 @@ def _explained_by_chroma(ref_bgr, U, V):
     of the uint8 bicubic chroma planes that needs no GP fit (a wrong U or V leaves no Y that reproduces all three
     channels)."""
     ok = np.zeros(ref_bgr.shape[:2], bool)
-    for Y in range(256):
-        ok |= (cvops.yuv2bgr(np.stack([np.full(U.shape, Y, np.uint8), U, V], -1)) == ref_bgr).all(-1)
+    y0 = cvops.bgr2yuv(ref_bgr)[..., 0].astype(int)          # the luma is within a few levels of this one
+    for dy in range(-4, 5):
+        Y = np.clip(y0 + dy, 0, 255).astype(np.uint8)
+        ok |= (cvops.yuv2bgr(np.stack([Y, U, V], -1)) == ref_bgr).all(-1)
+    rest = np.nonzero(~ok)                                    # whatever is left: every luma, on those pixels only
+    if rest[0].size:
+        r, u, v = ref_bgr[rest][:, None, :], U[rest][:, None], V[rest][:, None]
+        good = np.zeros(rest[0].size, bool)
+        for Y in range(256):
+            good |= (cvops.yuv2bgr(np.stack([np.full(u.shape, Y, np.uint8), u, v], -1)) == r).all(-1)[:, 0]
+        ok[rest] = good
     return float(ok.mean())
 
 
