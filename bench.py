@@ -191,10 +191,16 @@ def main(argv=None):
     ap.add_argument("--warm-start", default="independent", choices=("independent", "chain_per_image", "chain"))
     ap.add_argument("--synthetic", action="store_true", help="synthetic images of the Set14 shapes instead of the fixtures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-reference-check", action="store_true",
+                    help="skip the untimed runs against the reference's own PNGs (parity.*vs_reference_png): under rocprofv3 "
+                         "their launches would enter the per-kernel averages of the profile")
     ap.add_argument("--scaling", choices=("weak", "strong"), default=None,
                     help="N > 1: weak = N copies of the workload (default for set14x3); strong = ONE copy whose patches "
                          "are sharded over the N ranks (default for 4kx2 = BASELINE config 4: one 4K image at 1/2/4/8 GPUs)")
     ap.add_argument("--max-workspace-gb", type=float, default=48.0)
+    ap.add_argument("--no-split-small", action="store_true",
+                    help="gpsr_set_split_small(0): every launch takes the whole batch on one stream (the default issues the "
+                         "runs of small launches -- pivot / panel / restricted update -- as two halves on two streams)")
     ap.add_argument("--dual-stream", action="store_true",
                     help="gpsr_set_dual_stream(1): two half-batches on two streams (+5 %% throughput; per-launch "
                          "durations then overlap, so the roofline object describes launches that share the GPU)")
@@ -230,6 +236,7 @@ def main(argv=None):
     kern = {"matern52": K.matern52_kernel, "matern32": K.matern32_kernel, "rbf": K.rbf_kernel,
             "exponential": K.exponential_kernel}[kname]
     ops.set_dual_stream(a.dual_stream)
+    ops.set_split_small(not a.no_split_small)
     copies = world if a.scaling == "weak" else 1
     imgs_u8, s, data_desc = workload(a.workload, copies, a.synthetic)
     n_base = len(imgs_u8) // copies
@@ -312,7 +319,8 @@ def main(argv=None):
     # reference committed as img_001_SRF_3_GPR_matern52.png (fixture refout_m52_001.png); the chained modes must reproduce it
     # from the colour LR file through BGR2GRAY (the grey lr_*.png fixtures above were made with another grey table)
     ref_lr, ref_png = os.path.join(ROOT, "tests", "golden", "refpin", "x3_lr_001.png"), os.path.join(GOLDEN, "refout_m52_001.png")
-    if (parity is not None and a.warm_start in ("chain", "chain_per_image") and os.path.exists(ref_lr) and os.path.exists(ref_png)):
+    if (parity is not None and not a.no_reference_check and a.warm_start in ("chain", "chain_per_image")
+            and os.path.exists(ref_lr) and os.path.exists(ref_png)):
         from PIL import Image
         bgr = torch.as_tensor(np.ascontiguousarray(np.array(Image.open(ref_lr).convert("RGB"))[:, :, ::-1])).to(dev)
         g1 = GPRSR(s, kern, ColorSpace.GRAYSCALE, warm_start="chain_per_image")
@@ -326,7 +334,8 @@ def main(argv=None):
     # independent starts: the reference output this MODE reproduces is a x2 YUV / BILINEAR one (an earlier state of the
     # reference) -- not this workload's configuration, recorded as the mode's pin (untimed, 0.1 s)
     ref_lr, ref_png = (os.path.join(ROOT, "tests", "golden", "refpin", n) for n in ("x2_lr_001.png", "x2_ref_matern52_yuv_001.png"))
-    if parity is not None and a.warm_start == "independent" and os.path.exists(ref_lr) and os.path.exists(ref_png):
+    if (parity is not None and not a.no_reference_check and a.warm_start == "independent"
+            and os.path.exists(ref_lr) and os.path.exists(ref_png)):
         from PIL import Image
         from super_resolution_amd import gprsr as _gprsr
         from super_resolution_amd.image_patches import PatchInterpolationMode
@@ -402,7 +411,7 @@ def main(argv=None):
             "config": {"workload": f"{a.workload}: {len(imgs_u8)} images, {n_patches} patches, "
                                    f"{2 * n_patches} GP fits (n={n}), {out_px / 1e6:.4f} output Mpx",
                        "kernel": kname,
-                       "color": "GRAYSCALE", "warm_start": a.warm_start, "dual_stream": bool(a.dual_stream),
+                       "color": "GRAYSCALE", "warm_start": a.warm_start, "dual_stream": bool(a.dual_stream), "split_small": not a.no_split_small,
                        "parallelism": (f"patch-sharded x{world}" if a.warm_start == "independent"
                                        else f"whole chains dealt to {world} rank(s)"),
                        "ranks_in_process_group": ranks_seen, "backend": backend},

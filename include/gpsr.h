@@ -187,6 +187,17 @@ int gpsr_fit_noalloc(const double* X, const double* y, int B, int n, int d, int 
 int gpsr_set_dual_stream(int on);
 
 /*
+ * On by default: gpsr_fit on a batch of >= 256 GPs issues the runs of SMALL launches between the chip-filling ones
+ * (pivot, panel, restricted update, pivot, panel: latency-bound workgroups that end in half-empty rounds) for the two
+ * halves of the batch on two streams (the caller's and an internal one, forked from and joined to it with events
+ * around each run); the big launches -- covariance, the full updates, the gradient pass -- take the whole batch on the
+ * caller's stream alone, so their per-launch durations (gpsr_profile_*) still measure one kernel.  Results are
+ * bit-identical.  gpsr_set_split_small(0) (or GPSR_NO_SPLIT_SMALL=1 in the environment) turns it off; process-wide,
+ * returns the previous setting.  No counterpart in the reference.
+ */
+int gpsr_set_split_small(int on);
+
+/*
  * One evaluation of the loss and of d loss / d raw (no Adam step), for tests:
  * what loss.backward() leaves in .grad at gprsr.py:185.   grad : [B][4] float32
  */

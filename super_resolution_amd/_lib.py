@@ -40,6 +40,7 @@ SIGNATURES = {
     "gpsr_fit_noalloc": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_int, c_float,
                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "gpsr_set_dual_stream": (c_int, [c_int]),
+    "gpsr_set_split_small": (c_int, [c_int]),
     "gpsr_loss_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "gpsr_predict": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p]),

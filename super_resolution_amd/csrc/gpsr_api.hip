@@ -264,6 +264,8 @@ struct Op { int kind, k, set, arg; bool heavy; };   // set: which (U, M, Wo) tri
 
 struct Batch {   // one batch (or half-batch) of GPs and its buffers
   int B;
+  int Bdec;   // 0, or the size of the whole batch this one is a slice of: launch-shape decisions that two launches of
+              // one pivot step must agree on (who forms tile (k,k)) are taken on it
   const double *X, *y;
   float* raw;
   double *alpha, *loss;
@@ -349,6 +351,7 @@ static int launch_grad2(const FitWs& w, const double* X, const float* raw, const
 
 static int launch_op(const Op& op, const Batch& h, const FitShape& c) {
   const int B = h.B, N = c.N, nblk = N / NB, ntri1 = (nblk - 1) * nblk / 2, ntri = nblk * (nblk + 1) / 2;
+  const int Bd = h.Bdec ? h.Bdec : h.B;
   const FitWs& w = h.w;
   hipStream_t st = h.st;
   double* Wo = op.set ? w.inv.Wo2 : w.inv.Wo;
@@ -357,7 +360,7 @@ static int launch_op(const Op& op, const Batch& h, const FitShape& c) {
     case OP_BUILD:
       return launch_build(h.X, B, c.n, N, c.d, c.kid, h.raw, w.A, w.logdet, st, 0);   // diagonal tiles: lower sub-blocks only
     case OP_PIVOT:
-      return launch_pivot(w.A, B, N, op.k, w.inv.U[op.set], w.inv.M[op.set], w.logdet, h.flags, update_forms_ptile(op.arg, B, nblk) ? 0 : (op.k == nblk - 1 ? 2 : 1), st);
+      return launch_pivot(w.A, B, N, op.k, w.inv.U[op.set], w.inv.M[op.set], w.logdet, h.flags, update_forms_ptile(op.arg, Bd, nblk) ? 0 : (op.k == nblk - 1 ? 2 : 1), st);
     case OP_PANEL:
       return launch_panel(w.A, B, N, op.k, w.inv.U[op.set], Wo, st);
     case OP_UPD_SEL: {
@@ -374,7 +377,7 @@ static int launch_op(const Op& op, const Batch& h, const FitShape& c) {
       return 0;
     }
     case OP_UPD2: {
-      const int pt = update_forms_ptile(PT_UPD2, B, nblk) ? 1 : 0;
+      const int pt = update_forms_ptile(PT_UPD2, Bd, nblk) ? 1 : 0;
       const int nb2 = nblk - 2, per = nb2 * (nb2 + 1) / 2 + nb2 + 1 + nblk - 1 + pt, tu = per * B;
       pr = prof_start(T_UPDATE2, st);
       if (strip_mode(tu))
@@ -388,7 +391,7 @@ static int launch_op(const Op& op, const Batch& h, const FitShape& c) {
       return 0;
     }
     case OP_UPD: {
-      const int pt = (!op.arg && update_forms_ptile(PT_UPD, B, nblk)) ? 1 : 0;   // + tile (k,k), see mark_pivots
+      const int pt = (!op.arg && update_forms_ptile(PT_UPD, Bd, nblk)) ? 1 : 0;   // + tile (k,k), see mark_pivots
       const int tu = (ntri1 + nblk - 1 + pt) * B;
       pr = prof_start(op.arg ? T_UPDATE_LAST : T_UPDATE, st);
       if (op.arg)
@@ -519,6 +522,77 @@ static int run_dual(const std::vector<Op>& ops, const Batch& a, Batch b, const F
   return 0;
 }
 
+// Default schedule of a large batch: the launches that fill the chip (covariance, the big updates, the gradient pass)
+// take the whole batch on the caller's stream, so their durations measure one kernel; the runs of small launches in
+// between -- pivot, panel, restricted update, pivot, panel: latency-bound workgroups that end in half-empty rounds
+// (633 pivots on 512 slots) -- are issued for the two halves of the batch on two streams, forked from and joined
+// to the caller's stream around each run, so that one half's panel fills the slots the other half's pivots leave.
+// Same kernels on the same per-GP data: bit-identical.  gpsr_set_split_small(0) / GPSR_NO_SPLIT_SMALL=1 turn it off.
+static int g_split_small = getenv("GPSR_NO_SPLIT_SMALL") == nullptr ? 1 : 0;
+
+extern "C" int gpsr_set_split_small(int on) {
+  const int old = g_split_small;
+  g_split_small = on ? 1 : 0;
+  return old;
+}
+
+static Batch slice_batch(const Batch& h, int b0, int nb, const FitShape& c) {
+  const int N = c.N, nblk = N / NB, ntri = nblk * (nblk + 1) / 2, per = (nblk - 1) * nblk / 2 + nblk - 1;
+  Batch s = h;
+  s.B = nb; s.Bdec = h.Bdec ? h.Bdec : h.B;
+  const size_t o = (size_t)b0;
+  if (h.X) s.X = h.X + o * c.n * c.d;
+  if (h.y) s.y = h.y + o * c.n;
+  if (h.raw) s.raw = h.raw + 4 * o;
+  if (h.alpha) s.alpha = h.alpha + o * N;
+  if (h.loss) s.loss = h.loss + o;
+  if (h.grad) s.grad = h.grad + 4 * o;
+  if (h.flags) s.flags = h.flags + o;
+  s.w.A = h.w.A + o * N * N;
+  s.w.inv.Wo = h.w.inv.Wo + o * NB * N;
+  s.w.inv.Wo2 = h.w.inv.Wo2 + o * NB * N;
+  for (int i = 0; i < 2; ++i) { s.w.inv.U[i] = h.w.inv.U[i] + o * NB * NB; s.w.inv.M[i] = h.w.inv.M[i] + o * NB * NB; }
+  if (h.w.stats1) s.w.stats1 = h.w.stats1 + o * nblk * 4;
+  if (h.w.stats2) s.w.stats2 = h.w.stats2 + o * ntri * 2;
+  if (h.w.logdet) s.w.logdet = h.w.logdet + o;
+  if (h.w.part) s.w.part = h.w.part + o * (per > 0 ? per : 1) * 2 * NB;
+  if (h.w.m1) s.w.m1 = h.w.m1 + 4 * o;
+  if (h.w.m2) s.w.m2 = h.w.m2 + 4 * o;
+  return s;
+}
+
+static int run_split_small(const std::vector<Op>& ops, const Batch& full, const FitShape& c, SideStream* ss) {
+  int rc = ensure_lds_attrs();
+  if (rc) return rc;
+  const int Ba = (full.B + 1) / 2;   // uneven cuts (512 + 121, 384 + 249, 256 + 377 of 633) measured the same or worse
+  Batch a = slice_batch(full, 0, Ba, c), b = slice_batch(full, Ba, full.B - Ba, c);
+  b.st = ss->s;
+  hipError_t e;
+  const size_t n = ops.size();
+  size_t i = 0;
+  while (i < n) {
+    size_t j = i;
+    bool has_pivot = false;
+    while (j < n && !ops[j].heavy) { has_pivot |= ops[j].kind == OP_PIVOT; ++j; }
+    if (j == i) { if ((rc = launch_op(ops[i], full, c))) return rc; ++i; continue; }
+    if (!has_pivot) {   // grad1 / adam alone: nothing to overlap
+      for (; i < j; ++i) if ((rc = launch_op(ops[i], full, c))) return rc;
+      continue;
+    }
+    if ((e = hipEventRecord(ss->fork, full.st)) != hipSuccess) return hip_fail(e, "fork record");
+    if ((e = hipStreamWaitEvent(b.st, ss->fork, 0)) != hipSuccess) return hip_fail(e, "fork wait");
+    // op by op, first half then second half: the host alternates, the two streams drain side by side
+    for (size_t t = i; t < j; ++t) {
+      if ((rc = launch_op(ops[t], a, c))) return rc;
+      if ((rc = launch_op(ops[t], b, c))) return rc;
+    }
+    if ((e = hipEventRecord(ss->join, b.st)) != hipSuccess) return hip_fail(e, "join record");
+    if ((e = hipStreamWaitEvent(full.st, ss->join, 0)) != hipSuccess) return hip_fail(e, "join wait");
+    i = j;
+  }
+  return 0;
+}
+
 extern "C" size_t gpsr_invert_workspace_bytes(int B, int n) {
   if (B <= 0 || n <= 0) return 0;
   return inv_ws_bytes(B, gpsr_padded_n(n));
@@ -582,7 +656,10 @@ extern "C" int gpsr_fit(const double* X, const double* y, int B, int n, int d, i
   a.w = fit_ws_carve((char*)workspace, Ba, N);
   e = hipMemsetAsync(a.w.m1, 0, 2 * align256((size_t)Ba * 16), st);
   if (e != hipSuccess) return hip_fail(e, "memset adam state");
-  if (!ss) return run_single(ops, a, c);
+  if (!ss) {
+    SideStream* sp = (g_split_small && nblk > 1 && B >= 2 * DUAL_MIN_B) ? side_stream() : nullptr;
+    return sp ? run_split_small(ops, a, c, sp) : run_single(ops, a, c);
+  }
   Batch b = {};
   b.B = B - Ba; b.X = X + (size_t)Ba * n * d; b.y = y + (size_t)Ba * n; b.raw = raw + 4 * (size_t)Ba;
   b.alpha = alpha + (size_t)Ba * N; b.loss = loss ? loss + Ba : nullptr; b.flags = flags + Ba;

@@ -148,6 +148,11 @@ def set_dual_stream(on):
     return bool(_lib.load().gpsr_set_dual_stream(1 if on else 0))
 
 
+def set_split_small(on):
+    """gpsr_set_split_small: the small launches of a big batch as two halves on two streams (default on). Returns the previous setting."""
+    return bool(_lib.load().gpsr_set_split_small(1 if on else 0))
+
+
 def loss_grad(X, y, kernel_id, raw, workspace=None):
     lib = _lib.load()
     B, n, d = X.shape

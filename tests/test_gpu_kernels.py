@@ -328,6 +328,31 @@ def test_fit_dual_stream_bit_identical():
     assert int(outs[0][2].sum()) == 0
 
 
+@pytest.mark.parametrize("B,n", [(300, 324), (257, 784), (400, 196)])
+def test_fit_split_small_bit_identical(B, n):
+    """gpsr_set_split_small (the default schedule of a batch >= 256): the runs of small launches as two half-batches
+    on two streams, the big launches on the whole batch -- the same bits as every launch on one stream, odd batch
+    sizes and 2, 3 and 7 block matrices included."""
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(B)
+    X = to_dev(rng.random((B, n, 8)))
+    y = to_dev(rng.random((B, n)))
+    raw0 = ops.init_hypers(y, ops.MATERN32)
+    outs = []
+    for split in (False, True):
+        prev = ops.set_split_small(split)
+        try:
+            raw = raw0.clone()
+            alpha, flags, loss = ops.fit(X, y, ops.MATERN32, raw, iters=2, want_loss=True)
+            torch.cuda.synchronize()
+            outs.append((alpha.clone(), raw.clone(), flags.clone(), loss.clone()))
+        finally:
+            ops.set_split_small(prev)
+    for u, v in zip(outs[0], outs[1]):
+        assert torch.equal(u, v)
+    assert int(outs[0][2].sum()) == 0
+
+
 def test_context_workspace_and_flag_count():
     """gpsr_create / gpsr_destroy: the library-owned workspace gives the same fit as a caller-owned one;
     gpsr_flag_count is the synchronising read-out of the per-GP failure flags."""

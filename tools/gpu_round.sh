@@ -17,8 +17,8 @@ timeout -k 10 400 python -u bench.py --workload 4kx2 --steps 1 --warmup 1 --no-c
 cut -c1-400 gpurun_out/${R}_bench_4kx2.json
 ROOT=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_indep -o indep -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline > $ROOT/gpurun_out/${R}_bench_set14x3_under_rocprof.json 2> $ROOT/gpurun_out/prof_indep.log || { echo rocprof indep failed; tail -5 $ROOT/gpurun_out/prof_indep.log; exit 1; }
-timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_chain -o chain -- python3 $ROOT/bench.py --warm-start chain_per_image --steps 1 --warmup 0 --no-cpu-baseline > $ROOT/gpurun_out/prof_chain.json 2> $ROOT/gpurun_out/prof_chain.log || { echo rocprof chain failed; tail -5 $ROOT/gpurun_out/prof_chain.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_indep -o indep -- python3 $ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-reference-check > $ROOT/gpurun_out/${R}_bench_set14x3_under_rocprof.json 2> $ROOT/gpurun_out/prof_indep.log || { echo rocprof indep failed; tail -5 $ROOT/gpurun_out/prof_indep.log; exit 1; }
+timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $ROOT/gpurun_out/prof_chain -o chain -- python3 $ROOT/bench.py --warm-start chain_per_image --steps 1 --warmup 0 --no-cpu-baseline --no-reference-check > $ROOT/gpurun_out/prof_chain.json 2> $ROOT/gpurun_out/prof_chain.log || { echo rocprof chain failed; tail -5 $ROOT/gpurun_out/prof_chain.log; exit 1; }
 cd $ROOT
 if [ "${SKIP_PMC:-0}" != "1" ]; then
 bash tools/pmc_run.sh gpurun_out/pmc324 10800 324 eval && python3 tools/pmc_summarize.py gpurun_out/pmc324 gpurun_out/${R}_pmc_eval_10800x324.json 10800 324 eval || exit 1
