@@ -198,6 +198,19 @@ int gpsr_set_dual_stream(int on);
 int gpsr_set_split_small(int on);
 
 /*
+ * Opt-in, off by default (GPSR_FUSED=1 in the environment turns it on): the fused per-GP route of gpsr_fit
+ * (k_fit_fused; no counterpart in the reference).  ONE launch runs the whole fit -- one workgroup per GP through
+ * covariance, sweep, alpha, gradient statistics and the Adam step of every iteration, a persistent grid of two
+ * workgroups per CU walking the batch, the matrix and panels in a per-workgroup-slot workspace that stays in L2 /
+ * Infinity Cache -- instead of ~650 launches that each stream the whole batch through HBM.  Same role functions on the
+ * same data in the same order: bit-identical to the launch-per-step route.  Used when on and d == 8, N >= 224.
+ * Measured slower than the default route on MI355X, hence opt-in.  Process-wide, returns the
+ * previous setting.  gpsr_fit_workspace_bytes / gpsr_predict_pixels_workspace_bytes follow the current setting (the
+ * fused route needs min(B, 2 x CUs) matrix slots + 32 bytes per GP): size the workspace after setting it.
+ */
+int gpsr_set_fused(int on);
+
+/*
  * One evaluation of the loss and of d loss / d raw (no Adam step), for tests:
  * what loss.backward() leaves in .grad at gprsr.py:185.   grad : [B][4] float32
  */
@@ -360,6 +373,7 @@ enum {
   GPSR_PROF_UPDATE_LAST, /* k_update<true>: the last pivot step's launch, which also leaves the alpha partials */
   GPSR_PROF_UPDATE2,     /* k_update2: both rank-112 updates of a two-pivot step in one pass over A */
   GPSR_PROF_UPDATE_SEL,  /* k_update restricted to the next pivot's block row/column (first half of a two-pivot step) */
+  GPSR_PROF_FUSED,       /* k_fit_fused: a whole fit (<= 128 Adam iterations + the final evaluation) of the batch */
   GPSR_PROFILE_NTAGS
 };
 int gpsr_profile_begin(int max_records);

@@ -41,6 +41,7 @@ SIGNATURES = {
                                  c_void_p, c_void_p, c_void_p, c_void_p]),
     "gpsr_set_dual_stream": (c_int, [c_int]),
     "gpsr_set_split_small": (c_int, [c_int]),
+    "gpsr_set_fused": (c_int, [c_int]),
     "gpsr_loss_grad": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p,
                                c_void_p, c_void_p, c_size_t, c_void_p]),
     "gpsr_predict": (c_int, [c_void_p] * 4 + [c_int] * 4 + [c_void_p, c_void_p]),

@@ -30,7 +30,7 @@ static inline size_t align256(size_t x) { return (x + 255) & ~(size_t)255; }
 // Optional HIP-event brackets around tagged launches, on the stream the kernel is
 // launched on.  Off by default; costs two hipEventRecord per tagged launch when on.
 #include <vector>
-enum { T_UPDATE = 0, T_PANEL, T_PIVOT, T_BUILD, T_GRAD1, T_GRAD2, T_PREDICT, T_UPDATE_LAST, T_UPDATE2, T_UPDATE_SEL, T_NTAGS };
+enum { T_UPDATE = 0, T_PANEL, T_PIVOT, T_BUILD, T_GRAD1, T_GRAD2, T_PREDICT, T_UPDATE_LAST, T_UPDATE2, T_UPDATE_SEL, T_FUSED, T_NTAGS };
 struct ProfRec { hipEvent_t a, b; int tag; };
 static std::vector<ProfRec> g_prof;
 static size_t g_prof_used = 0;
@@ -229,8 +229,47 @@ static size_t fit_ws_bytes1(int B, int N) {
          align256((size_t)B * ntri * 2 * 8) + align256((size_t)B * 8) + part_bytes(B, nblk) +
          2 * align256((size_t)B * 4 * 4);
 }
+// ---- fused per-GP route (k_fit_fused; opt-in): ONE launch per fit, one workgroup per GP, a persistent grid of two
+// workgroups per CU; the workspace is per SLOT (resident workgroup), not per GP.  Built to take the n = 324 path
+// (BASELINE config 4) off HBM -- the launch-per-step route streams the whole batch through HBM a dozen times per
+// evaluation -- and it does (0.9 GiB of workspace instead of 19 GiB for 10 800 GPs, re-read out of L2 / Infinity Cache),
+// but measured on MI355X it is SLOWER: 2.0 us per GP-evaluation against 1.585 (10 800 GPs of n = 324, Matern-3/2).
+// tools/fused_trace.py shows why: with two workgroups per CU (LDS and the 128-register budget allow no more) nothing
+// hides a role's own latencies -- the first DMA chunk, the drain of its stores before the next role may read them,
+// the global loads of the gradient pass -- which the launch-per-step route hides behind the other 10 000 workgroups of
+// the launch.  Kept as a tested, bit-identical, opt-in route: gpsr_set_fused(1) / GPSR_FUSED=1;
+// GPSR_FUSED_STAGGER is a tuning switch.
+static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
+static int g_fused_mode = env_int("GPSR_FUSED", 0) ? 1 : 0;
+static const int g_fused_stagger = env_int("GPSR_FUSED_STAGGER", 24);
+
+extern "C" int gpsr_set_fused(int on) {
+  const int old = g_fused_mode;
+  g_fused_mode = on ? 1 : 0;
+  return old;
+}
+static bool fused_applies(int B, int N, int d) {
+  (void)B;
+  return g_fused_mode != 0 && d == 8 && N / NB >= 2;
+}
+static int fused_slots() {   // two workgroups per CU (76 KB of LDS each)
+  static int slots[64] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 512;
+  if (!slots[dev]) {
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+    slots[dev] = 2 * cus;
+  }
+  return slots[dev];
+}
+static size_t fused_ws_bytes(int B, int N) {
+  const int S = B < fused_slots() ? B : fused_slots();
+  return fit_ws_bytes1(S, N) + 2 * align256((size_t)B * 16);   // + the Adam moments of every GP
+}
 // the fit may run its batch as two halves with a workspace each (run_dual)
-static size_t fit_ws_bytes(int B, int N) {
+static size_t fit_ws_bytes(int B, int N, int d) {
+  if (fused_applies(B, N, d)) return fused_ws_bytes(B, N);
   const size_t one = fit_ws_bytes1(B, N), two = fit_ws_bytes1((B + 1) / 2, N) + fit_ws_bytes1(B / 2 > 0 ? B / 2 : 1, N);
   return one > two ? one : two;
 }
@@ -249,9 +288,8 @@ static FitWs fit_ws_carve(char* base, int B, int N) {
 }
 
 extern "C" size_t gpsr_fit_workspace_bytes(int B, int n, int d) {
-  (void)d;
   if (B <= 0 || n <= 0) return 0;
-  return fit_ws_bytes(B, gpsr_padded_n(n));
+  return fit_ws_bytes(B, gpsr_padded_n(n), d);
 }
 
 // ---------------------------------------------------------------- launch sequence
@@ -624,7 +662,70 @@ static int check_fit_args(const double* X, const double* y, int B, int n, int d,
   if (!X || !y || !ws) return arg_fail("null pointer");
   if (n < 2 || d < 1 || d > 64 || kid < 0 || kid > 4) return arg_fail("fit shape / kernel_id");
   if (gpsr_padded_n(n) > 16 * NB) return arg_fail("n too large (max 1792)");
-  if (wsb < fit_ws_bytes(B, gpsr_padded_n(n))) return arg_fail("workspace too small");
+  if (wsb < fit_ws_bytes(B, gpsr_padded_n(n), d)) return arg_fail("workspace too small");
+  return 0;
+}
+
+// One launch per <= FUSED_MAX_IT Adam iterations (the per-iteration constants travel as a kernel argument), the last
+// one also runs the evaluation at the final hyper-parameters.  The Adam moments of every GP live behind the slot
+// workspace so that a fit of more iterations can continue across launches.
+template <int KID>
+static int launch_fused(const double* X, const double* y, int B, int n, int N, float* raw, double* alpha, double* loss,
+                        int32_t* flags, float* m1g, float* m2g, int nit, int final_eval, const AdamTab& tab,
+                        const FusedWs& w, int slots, hipStream_t st) {
+  static bool attr_done[64] = {};
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  if (dev < 0 || dev >= 64 || !attr_done[dev]) {
+    e = hipFuncSetAttribute((const void*)k_fit_fused<KID>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)PIVOT_LDS_BYTES);
+    if (e != hipSuccess) return hip_fail(e, "fused lds attr");
+    if (dev >= 0 && dev < 64) attr_done[dev] = true;
+  }
+  ProfRec* pr = prof_start(T_FUSED, st);
+  hipLaunchKernelGGL((k_fit_fused<KID>), dim3(slots), dim3(MM_THREADS), PIVOT_LDS_BYTES, st, X, y, raw, alpha, loss, flags,
+                     m1g, m2g, B, n, N, nit, final_eval, tab, w, g_pair_steps ? 1 : 0, g_fused_stagger, (float)(1.0 - 0.9),
+                     (float)0.999, (float)(1.0 - 0.999), 1e-8f);
+  prof_stop(pr, st);
+  CHECK_LAUNCH("k_fit_fused");
+  return 0;
+}
+
+static int run_fused(const double* X, const double* y, int B, int n, int N, int kid, float* raw, int iters, float lr,
+                     double* alpha, double* loss, int32_t* flags, void* workspace, hipStream_t st) {
+  const int slots = B < fused_slots() ? B : fused_slots();
+  const FitWs fw = fit_ws_carve((char*)workspace, slots, N);
+  FusedWs w = {fw.A, fw.inv.Wo, fw.inv.Wo2, fw.inv.U[0], fw.inv.M[0], fw.inv.U[1], fw.inv.M[1],
+               fw.stats1, fw.stats2, fw.logdet, fw.part};
+  float* m1g = (float*)((char*)workspace + fit_ws_bytes1(slots, N));
+  float* m2g = (float*)((char*)m1g + align256((size_t)B * 16));
+  hipError_t e = hipMemsetAsync(m1g, 0, 2 * align256((size_t)B * 16), st);
+  if (e != hipSuccess) return hip_fail(e, "memset adam state");
+  int it = 0;
+  do {
+    const int nit = iters - it < FUSED_MAX_IT ? iters - it : FUSED_MAX_IT;
+    AdamTab tab;
+    for (int q = 0; q < nit; ++q) {   // as OP_ADAM: step number it + q + 1
+      const double b1 = 0.9, b2 = 0.999;
+      const double bc1 = 1.0 - pow(b1, it + q + 1), bc2 = 1.0 - pow(b2, it + q + 1);
+      tab.step[q] = (float)((double)lr / bc1);
+      tab.bc2s[q] = (float)sqrt(bc2);
+    }
+    for (int q = nit; q < FUSED_MAX_IT; ++q) { tab.step[q] = 0.f; tab.bc2s[q] = 1.f; }
+    const int fin = it + nit >= iters ? 1 : 0;
+    int rc;
+#define FUSED(K) rc = launch_fused<K>(X, y, B, n, N, raw, alpha, loss, flags, m1g, m2g, nit, fin, tab, w, slots, st)
+    switch (kid) {
+      case K_RBF: FUSED(K_RBF); break;
+      case K_M12: FUSED(K_M12); break;
+      case K_M32: FUSED(K_M32); break;
+      case K_M52: FUSED(K_M52); break;
+      default: FUSED(K_LIN); break;
+    }
+#undef FUSED
+    if (rc) return rc;
+    it += nit;
+  } while (it < iters);
   return 0;
 }
 
@@ -641,6 +742,8 @@ extern "C" int gpsr_fit(const double* X, const double* y, int B, int n, int d, i
   const int N = gpsr_padded_n(n), nblk = N / NB;
   hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
   if (e != hipSuccess) return hip_fail(e, "memset flags");
+  if (fused_applies(B, N, d))
+    return run_fused(X, y, B, n, N, kernel_id, raw, iters, lr, alpha, loss, flags, workspace, st);
   // `iters` Adam steps, then the final factorisation at the post-step hyper-parameters -> alpha
   std::vector<Op> ops;
   for (int it = 1; it <= iters; ++it) {
@@ -893,7 +996,7 @@ static size_t pix_ws_carve(char* base, int B, int Bc, int n, int m, PixWs* w) {
   CARVE(alpha, double*, (size_t)Bc * N * 8);
 #undef CARVE
   if (w) w->fit = base + off;
-  return off + fit_ws_bytes(Bc, N);
+  return off + fit_ws_bytes(Bc, N, 8);
 }
 
 extern "C" size_t gpsr_predict_pixels_workspace_bytes(int s, int p, int nt, int B, int chunk) {
@@ -922,7 +1025,7 @@ extern "C" int gpsr_predict_pixels(const double* train_in, const double* train_t
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(k_make_locs, dim3((B + 255) / 256), dim3(256), 0, st, rows, cols, nr, nc, w.locs);
   CHECK_LAUNCH("k_make_locs");
-  const size_t fit_bytes = fit_ws_bytes(Bc, N);
+  const size_t fit_bytes = fit_ws_bytes(Bc, N, 8);
   for (int b0 = 0; b0 < B; b0 += Bc) {
     const int bn = (B - b0 < Bc) ? B - b0 : Bc;
     int rc = gpsr_gather(train_in, train_tgt, test_in, H, W, s, p, w.locs + 2 * b0, bn, tidx, nt, w.X, w.y, w.Xs, stream);
@@ -1157,6 +1260,17 @@ extern "C" int gpsr_debug_upd_trace(unsigned long long* out8) {
   if (e != hipSuccess) return hip_fail(e, "trace read");
   unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   e = hipMemcpyToSymbol(HIP_SYMBOL(g_upd_trace), z, sizeof(z));
+  return e == hipSuccess ? 0 : hip_fail(e, "trace clear");
+}
+#endif
+
+#ifdef GPSR_FUSED_TRACE
+// debug build only (tools/fused_trace.py): read (and clear) the k_fit_fused role cycle counters
+extern "C" int gpsr_debug_fused_trace(unsigned long long* out16) {
+  hipError_t e = hipMemcpyFromSymbol(out16, HIP_SYMBOL(g_fused_trace), 16 * sizeof(unsigned long long));
+  if (e != hipSuccess) return hip_fail(e, "trace read");
+  unsigned long long z[16] = {};
+  e = hipMemcpyToSymbol(HIP_SYMBOL(g_fused_trace), z, sizeof(z));
   return e == hipSuccess ? 0 : hip_fail(e, "trace clear");
 }
 #endif

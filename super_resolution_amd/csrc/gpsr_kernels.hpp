@@ -320,15 +320,12 @@ __global__ void k_build_dl(const double* __restrict__ X, const float* __restrict
 // keeps column point x_j in registers and walks rows i = g, g+4, ...; the row point x_i
 // is an LDS broadcast (one address per wave, up to the g boundary).  Same per-element
 // arithmetic as k_build, element order only.
+// Role form (one tile by one 448-thread workgroup; LDS handed in) + the launch wrapper: the fused per-GP fit kernel
+// (k_fit_fused) runs the same role bodies one after the other, so both routes execute the same instructions.
 template <int KID>
-__global__ void __launch_bounds__(MM_THREADS)
-k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __restrict__ A, int n, int N,
-         int ntri, int total, double* __restrict__ logdet, int full_diag) {
-  __shared__ __attribute__((aligned(16))) double xi[NB * 8];
-  const int v = xcd_remap(blockIdx.x, total);
-  const int b = v / ntri, t = v % ntri;
-  int I, J; tri_decode(t, I, J);
-  const int tid = threadIdx.x;
+__device__ __forceinline__ void role_build8(const double* __restrict__ Xb, const float* __restrict__ rawb,
+                                            double* __restrict__ Agp, int n, int N, int I, int J, int full_diag,
+                                            double* __restrict__ xi, double* __restrict__ hs, int tid) {
   // Diagonal tiles inside the fit: the sweep reads only the 16x16 sub-blocks on and below the diagonal
   // (k_pivot, the SKIP_DIAG updates), so only those 28 of 49 are evaluated: 16 threads per sub-block, one
   // column each.  gpsr_covariance (full_diag) keeps whole diagonal tiles.
@@ -339,7 +336,6 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
     int bi, bj; tri_decode(tid >> 4, bi, bj);
     j = 16 * bj + (tid & 15); i0 = 16 * bi; istep = 1; iend = i0 + 16; g = 0;
   }
-  const double* Xb = X + (size_t)b * n * 8;
   const int gj = J * NB + j;
   double xj[8];
 #pragma unroll
@@ -348,12 +344,10 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
     const int gi = I * NB + (e >> 3);
     xi[e] = gi < n ? Xb[(size_t)I * NB * 8 + e] : 0.0;
   }
-  __shared__ double hs[6];
-  load_hyp_shared_put(raw + 4 * b, hs, tid);
-  if (t == 0 && tid == 0 && logdet) logdet[b] = 0.0;
+  load_hyp_shared_put(rawb, hs, tid);
   __syncthreads();
   const Hyp h = load_hyp_shared_get(hs);
-  double* Ab = A + (size_t)b * N * N + TILE_OFF(I, J, N / NB) + j;
+  double* Ab = Agp + TILE_OFF(I, J, N / NB) + j;
   // Rows of real points first, padding rows (identity) after; an off-diagonal tile has no diagonal element, so its
   // loop carries neither the noise term nor any per-element test (same arithmetic per element; the tests and the
   // select cost a fifth of the instructions of the loop).
@@ -378,6 +372,20 @@ k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __
   int ipad = i0;                                       // first row of this thread's walk that is padding
   if (gj < n && ireal > i0) ipad = i0 + ((ireal - i0 + istep - 1) / istep) * istep;
   for (int i = ipad; i < iend; i += istep) Ab[(size_t)i * NB] = (I == J && i == j) ? 1.0 : 0.0;
+}
+
+template <int KID>
+__global__ void __launch_bounds__(MM_THREADS)
+k_build8(const double* __restrict__ X, const float* __restrict__ raw, double* __restrict__ A, int n, int N,
+         int ntri, int total, double* __restrict__ logdet, int full_diag) {
+  __shared__ __attribute__((aligned(16))) double xi[NB * 8];
+  __shared__ double hs[6];
+  const int v = xcd_remap(blockIdx.x, total);
+  const int b = v / ntri, t = v % ntri;
+  int I, J; tri_decode(t, I, J);
+  const int tid = threadIdx.x;
+  if (t == 0 && tid == 0 && logdet) logdet[b] = 0.0;
+  role_build8<KID>(X + (size_t)b * n * 8, raw + 4 * b, A + (size_t)b * N * N, n, N, I, J, full_diag, xi, hs, tid);
 }
 
 // ------------------------------------------------------------ pivot block
@@ -559,18 +567,17 @@ __device__ __forceinline__ void store_mu_block(double* __restrict__ Mb, double* 
   }
 }
 
-__global__ void __launch_bounds__(MM_THREADS, 4)
-k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double* __restrict__ Mbuf,
-        double* __restrict__ logdet, int32_t* __restrict__ flags, int with_p) {
-  extern __shared__ double sm[];
+// Akk: the pivot tile (contiguous [NB][NB]); Ub, Mb, logdet_b, flags_b: this GP's; sm: PIVOT_LDS_BYTES of LDS
+__device__ __forceinline__ void role_pivot(double* __restrict__ Akk, double* __restrict__ Ub, double* __restrict__ Mb,
+                                           double* __restrict__ logdet_b, int32_t* __restrict__ flags_b, int with_p,
+                                           double* __restrict__ sm) {
 #ifdef GPSR_PIV_TRACE
   unsigned long long piv_t = __builtin_readcyclecounter();
   const unsigned long long piv_t0 = piv_t;
 #endif
   double* S = sm;                           // [PV_NBLK][16][PV_DLD]
-  const int b = blockIdx.x, tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   const int lr = lane & 15, lk = lane >> 4;
-  double* Akk = A + (size_t)b * N * N + TILE_OFF(k, k, N / NB);   // the pivot tile: contiguous [NB][NB]
   // 28 blocks x 16 rows x 8 units of 16 B = 3584 units = 8 per thread: all 8 loads are issued
   // before the first LDS store, so the block arrives in one memory latency instead of sixteen
   {
@@ -593,8 +600,6 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   PIV_STAMP(1);
   double ld = 0.0;
   int bad = 0;
-  double* Ub = Ubuf + (size_t)b * NB * NB;
-  double* Mb = Mbuf + (size_t)b * NB * NB;
   double* stg = sm + PV_NBLK * PV_BLK + wave * PV_BLK;   // per-wave parking block
   // ---------------- phase 1: blocked Cholesky; afterwards SB(q,q) = inv(L16_q), SB(w,q) = L[w,q]
   // The 16x16 factor+inverse is a serial register kernel: ONE wave (the owner of the diagonal
@@ -773,8 +778,8 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
   __syncthreads();
   PIV_STAMP(4);
   if (tid == 0) {
-    logdet[b] += ld;
-    if (bad) flags[b] = 1;
+    *logdet_b += ld;
+    if (bad) *flags_b = 1;
   }
 #ifdef GPSR_PIV_TRACE
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -783,6 +788,15 @@ k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double*
 #endif
 }
 #define PIVOT_LDS_BYTES ((PV_NBLK * PV_BLK + NBT * PV_BLK) * sizeof(double))
+
+__global__ void __launch_bounds__(MM_THREADS, 4)
+k_pivot(double* __restrict__ A, int N, int k, double* __restrict__ Ubuf, double* __restrict__ Mbuf,
+        double* __restrict__ logdet, int32_t* __restrict__ flags, int with_p) {
+  extern __shared__ double sm[];
+  const int b = blockIdx.x;
+  role_pivot(A + (size_t)b * N * N + TILE_OFF(k, k, N / NB), Ubuf + (size_t)b * NB * NB, Mbuf + (size_t)b * NB * NB,
+             logdet + b, flags + b, with_p, sm);
+}
 
 
 // ------------------------------------------------- shared MFMA tile-product pieces
@@ -832,6 +846,14 @@ __device__ __forceinline__ void store_strip_transposed(const v4d acc[NBT], doubl
 // wave-uniform base + lane*16 B, so the image must be lane-linear); the MFMA operand reads
 // (16 consecutive doubles per 16-lane group, rows 896 B apart) are bank-conflict free.
 #define DMA_CHUNK (KC * NB)  // doubles per operand chunk
+// experiment switch (tools/fused_time.py): the chunk loops of the workgroup-form tile products rolled instead of unrolled
+#ifdef GPSR_ROLL_CHUNKS
+#define CHUNK_LOOP_U _Pragma("nounroll")
+#define CHUNK_LOOP_D _Pragma("nounroll")
+#else
+#define CHUNK_LOOP_U _Pragma("unroll")
+#define CHUNK_LOOP_D
+#endif
 
 __device__ __forceinline__ void dma_chunk(const double* __restrict__ Aop, int lda, const double* __restrict__ Bop,
                                           int ldb, int chunk, double* __restrict__ bufA, double* __restrict__ bufB,
@@ -882,6 +904,7 @@ __device__ __forceinline__ void tile_product_dma(const double* __restrict__ Aop,
                                                  v4d acc[NBT], int wave, int lane) {
   // lds: [2 buffers][A chunk | B chunk]
   dma_chunk(Aop, lda, Bop, ldb, 0, lds, lds + DMA_CHUNK, wave, lane);
+  CHUNK_LOOP_D
   for (int ch = 0; ch < NB / KC; ++ch) {
     double* cur = lds + (ch & 1) * 2 * DMA_CHUNK;
     double* nxt = lds + ((ch + 1) & 1) * 2 * DMA_CHUNK;
@@ -914,6 +937,7 @@ __device__ __forceinline__ void tile_product_dma_latec(const double* __restrict_
   chunk_mfma_dma<SKIP_NONE, true>(lds, lds + DMA_CHUNK, acc, wave, lane, 0);
 #pragma unroll
   for (int t = 0; t < NBT; ++t) acc[t] += c0[t];   // the compiler folds these in as each acc[t] finishes chunk 0
+  CHUNK_LOOP_D
   for (int ch = 1; ch < NB / KC; ++ch) {
     double* cur = lds + (ch & 1) * 2 * DMA_CHUNK;
     double* nxt = lds + ((ch + 1) & 1) * 2 * DMA_CHUNK;
@@ -1147,7 +1171,7 @@ __device__ __forceinline__ void tile_product_dma2(const double* __restrict__ A1,
 #ifdef GPSR_UPD_TRACE
   unsigned long long trc = 0;   // GPSR_UPD_TRACE == 1: s_waitcnt + barrier; == 2: LDS reads + MFMAs; == 3: DMA issue
 #endif
-#pragma unroll
+  CHUNK_LOOP_U
   for (int g = 0; g < 2 * NC; ++g) {
     double* cur = lds + (g & 1) * 2 * DMA_CHUNK;
     double* nxt = lds + ((g + 1) & 1) * 2 * DMA_CHUNK;
@@ -1221,35 +1245,23 @@ __device__ __forceinline__ void tile_product2(const double* __restrict__ A1, int
   else tile_product_dma2<SKIP1, NEG1, SKIP2, NEG2, LATEC>(A1, lda1, B1, ldb1, A2, lda2, B2, ldb2, lds, acc, Ct, ldc, wave, lane);
 }
 
-template <bool G1, bool STRIP>   // G1: last pivot step of a fit evaluation, leaves the alpha mat-vec partials (own
-                     // instantiation: the epilogue's registers must not weigh on the six launches that do not need it).
-                     // STRIP: one wave per workgroup, seven workgroups per tile (small batches; never with G1)
-__global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
-k_update(double* __restrict__ A, int N, int nblk, int k,
-             const double* __restrict__ Wo, const double* __restrict__ Mbuf, int ntri1, int total,
-             const double* __restrict__ y, const float* __restrict__ raw, int n, double* __restrict__ part,
-             int sel, int ptile) {   // ptile (sel < 0, never with G1): one more tile per GP, (k,k) = -M^T M
-  static_assert(!(G1 && STRIP), "the alpha epilogue reduces across the waves of a workgroup");
-  __shared__ __attribute__((aligned(16))) double lds[STRIP ? S_STAGES * SCH : 4 * DMA_CHUNK];   // strip form: 48 KB, three workgroups per CU
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int vv = xcd_remap(blockIdx.x, total);
-  const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int v = STRIP ? vv / NBT : vv;
-  // sel < 0: every tile of the step.  sel >= 0 (first half of a two-pivot step): only the nblk tiles that
-  // the NEXT pivot's panel reads, i.e. those of block row / column `sel`: the nblk-1 trailing tiles
-  // (sel, other) / (other, sel) and the pivot-column tile of row block sel.
-  const int per = sel < 0 ? ntri1 + nblk - 1 + ptile : nblk;
-  const int b = v / per, t0 = v % per;
-  double* Ab = A + (size_t)b * N * N;
+// Role form of one tile of a pivot step (k_update below is the launch wrapper).  Ab, Wob, Mb, yb, rawb, partb: this
+// GP's matrix, panel, pivot factor, targets, raw hyper-parameters and mat-vec partials; t0: the tile (see k_update);
+// lds: STRIP ? S_STAGES*SCH : 4*DMA_CHUNK doubles; rv: 2*NB doubles (G1 only).
+template <bool G1, bool STRIP>
+__device__ __forceinline__ void role_update(double* __restrict__ Ab, int nblk, int k, const double* __restrict__ Wob,
+                                            const double* __restrict__ Mb, int ntri1, int t0,
+                                            const double* __restrict__ yb, const float* __restrict__ rawb, int n,
+                                            double* __restrict__ partb, int sel, double* __restrict__ lds,
+                                            double* __restrict__ rv, int wave, int lane, int tid) {
   if constexpr (!G1) {
     if (sel < 0 && t0 == ntri1 + nblk - 1) {
-      form_ptile<STRIP>(Ab + TILE_OFF(k, k, nblk), Mbuf + (size_t)b * NB * NB, lds, wave, lane, true);
+      form_ptile<STRIP>(Ab + TILE_OFF(k, k, nblk), Mb, lds, wave, lane, true);
       return;
     }
   }
   const int lr = lane & 15, lk = lane >> 4;
   v4d acc[NBT];
-  __shared__ double rv[G1 ? 2 * NB : 1];   // G1 only: r = y - c of the tile's row and column blocks
   int I, J;
   bool trailing;
   if (sel < 0) {
@@ -1262,9 +1274,9 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
     else { I = sel; J = k; }
   }
   if (trailing) {
-    if (G1) grad1_stage_r(rv, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, J, tid);
-    const double* Aop = Wo + (size_t)b * NB * N + (size_t)I * (NB * NB);   // used negated
-    const double* Bop = Wo + (size_t)b * NB * N + (size_t)J * (NB * NB);
+    if (G1) grad1_stage_r(rv, yb, (double)rawb[1], n, I, J, tid);
+    const double* Aop = Wob + (size_t)I * (NB * NB);   // used negated
+    const double* Bop = Wob + (size_t)J * (NB * NB);
     double* Ct = Ab + TILE_OFF(I, J, nblk) + (size_t)(16 * wave + lk) * NB + lr;
     if (I == J) {
       // symmetric diagonal tile: wave w computes the 16x16 blocks t <= w and mirrors t < w
@@ -1287,7 +1299,7 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
         __syncthreads();   // chunk buffers are free: per-wave transposition scratch
         store_strip_transposed(acc, Ab + TILE_OFF(I, I, nblk), (size_t)NB, lds, wave, lane, 1.0, nullptr, wave);
       }
-      if (G1) grad1_partials(acc, true, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
+      if (G1) grad1_partials(acc, true, rv, lds, partb + (size_t)t0 * (2 * NB), wave, lane, tid);
     } else {
       tile_product_latec<STRIP>(Aop, NB, Bop, NB, lds, acc, Ct, (size_t)NB, wave, lane);
 #pragma unroll
@@ -1296,13 +1308,13 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
         for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
       if (G1) {
         __syncthreads();   // every wave is out of the chunk loop: the LDS buffers are free
-        grad1_partials(acc, false, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
+        grad1_partials(acc, false, rv, lds, partb + (size_t)t0 * (2 * NB), wave, lane, tid);
       }
     }
   } else {
-    if (G1) grad1_stage_r(rv, y + (size_t)b * n, (double)raw[4 * b + 1], n, I, k, tid);
-    const double* Aop = Wo + (size_t)b * NB * N + (size_t)I * (NB * NB);
-    const double* Bop = Mbuf + (size_t)b * NB * NB;
+    if (G1) grad1_stage_r(rv, yb, (double)rawb[1], n, I, k, tid);
+    const double* Aop = Wob + (size_t)I * (NB * NB);
+    const double* Bop = Mb;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
     tile_product<SKIP_LOWER, false, STRIP>(Aop, NB, Bop, NB, lds, acc, wave, lane);
@@ -1318,9 +1330,35 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
     }
     if (G1) {
       __syncthreads();
-      grad1_partials(acc, false, rv, lds, part + ((size_t)b * per + t0) * (2 * NB), wave, lane, tid);
+      grad1_partials(acc, false, rv, lds, partb + (size_t)t0 * (2 * NB), wave, lane, tid);
     }
   }
+}
+
+
+template <bool G1, bool STRIP>   // G1: last pivot step of a fit evaluation, leaves the alpha mat-vec partials (own
+                     // instantiation: the epilogue's registers must not weigh on the six launches that do not need it).
+                     // STRIP: one wave per workgroup, seven workgroups per tile (small batches; never with G1)
+__global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
+k_update(double* __restrict__ A, int N, int nblk, int k,
+             const double* __restrict__ Wo, const double* __restrict__ Mbuf, int ntri1, int total,
+             const double* __restrict__ y, const float* __restrict__ raw, int n, double* __restrict__ part,
+             int sel, int ptile) {   // ptile (sel < 0, never with G1): one more tile per GP, (k,k) = -M^T M
+  static_assert(!(G1 && STRIP), "the alpha epilogue reduces across the waves of a workgroup");
+  __shared__ __attribute__((aligned(16))) double lds[STRIP ? S_STAGES * SCH : 4 * DMA_CHUNK];   // strip form: 48 KB, three workgroups per CU
+  __shared__ double rv[G1 ? 2 * NB : 1];   // G1 only: r = y - c of the tile's row and column blocks
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int vv = xcd_remap(blockIdx.x, total);
+  const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int v = STRIP ? vv / NBT : vv;
+  // sel < 0: every tile of the step.  sel >= 0 (first half of a two-pivot step): only the nblk tiles that
+  // the NEXT pivot's panel reads, i.e. those of block row / column `sel`: the nblk-1 trailing tiles
+  // (sel, other) / (other, sel) and the pivot-column tile of row block sel.
+  const int per = sel < 0 ? ntri1 + nblk - 1 + ptile : nblk;
+  const int b = v / per, t0 = v % per;
+  role_update<G1, STRIP>(A + (size_t)b * N * N, nblk, k, Wo + (size_t)b * NB * N, Mbuf + (size_t)b * NB * NB, ntri1, t0,
+                         G1 ? y + (size_t)b * n : nullptr, G1 ? raw + 4 * b : nullptr, n,
+                         G1 ? part + (size_t)b * per * (2 * NB) : nullptr, sel, lds, rv, wave, lane, tid);
 }
 
 // ------------------------------------------------- update of two pivot steps at once
@@ -1334,26 +1372,18 @@ k_update(double* __restrict__ A, int N, int nblk, int k,
 //   (e) tile (k2,k2), with ptile:            A_k2k2 = -M2^T M2
 // Diagonal tiles: blocks on and below the diagonal only (no mirror: a single step always follows, see k_update).
 // grid.x = (ntri(nblk-2) + (nblk-2) + 1 + (nblk-1) + ptile) * B.
+// Role form of one tile of the fused update (k_update2 below is the launch wrapper): Ab, W1, W2, M1, M2 are this GP's.
 template <bool STRIP>
-__global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
-k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restrict__ Wo1,
-          const double* __restrict__ Wo2, const double* __restrict__ M1buf, const double* __restrict__ M2buf,
-          int total, int ptile) {   // ptile: the pivots left tiles (k1,k1), (k2,k2) to this launch (roles (c'), (e))
-  __shared__ __attribute__((aligned(16))) double lds[STRIP ? S_STAGES * SCH : 4 * DMA_CHUNK];   // strip form: 48 KB, three workgroups per CU
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int vv = xcd_remap(blockIdx.x, total);
-  const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
+__device__ __forceinline__ void role_update2(double* __restrict__ Ab, int nblk, int k1, const double* __restrict__ W1,
+                                             const double* __restrict__ W2, const double* __restrict__ M1,
+                                             const double* __restrict__ M2, int t0, int ptile,
+                                             double* __restrict__ lds, int wave, int lane) {
 #ifdef GPSR_UPD_TRACE
   const unsigned long long trc_t0 = TRC_CLK();
 #endif
   const int lr = lane & 15, lk = lane >> 4;
-  const int v = STRIP ? vv / NBT : vv;
   const int k2 = k1 + 1, nb2 = nblk - 2, ntri2 = nb2 * (nb2 + 1) / 2;
   const int per = ntri2 + nb2 + 1 + nblk - 1 + ptile;
-  const int b = v / per, t0 = v % per;
-  double* Ab = A + (size_t)b * N * N;
-  const double* W1 = Wo1 + (size_t)b * NB * N;
-  const double* W2 = Wo2 + (size_t)b * NB * N;
 #define WT(I) ((size_t)(I) * (NB * NB))   // row block I of a tile-blocked panel
   v4d acc[NBT];
   if (t0 < ntri2) {                                   // (a)
@@ -1402,7 +1432,7 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
     int I = t0 - ntri2; if (I >= k1) I += 2;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_product2<SKIP_LOWER, false, SKIP_NONE, true, false, STRIP>(W1 + WT(I), NB, M1buf + (size_t)b * NB * NB, NB,
+    tile_product2<SKIP_LOWER, false, SKIP_NONE, true, false, STRIP>(W1 + WT(I), NB, M1, NB,
                                                                     W2 + WT(I), NB, W2 + WT(k1), NB, lds, acc, nullptr,
                                                                     0, wave, lane);
     if (I > k1) {
@@ -1420,7 +1450,6 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
     if (ptile) {
 #pragma unroll
       for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-      const double* M1 = M1buf + (size_t)b * NB * NB;
       tile_product2<SKIP_PTP, true, SKIP_DIAG, true, false, STRIP>(M1, NB, M1, NB, W2 + WT(k1), NB, W2 + WT(k1), NB, lds, acc,
                                                                    nullptr, 0, wave, lane);
     } else {   // -P1 is there (k_pivot with_p)
@@ -1437,12 +1466,12 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
       for (int rr = 0; rr < 4; ++rr) Ct[(size_t)(4 * rr) * NB + 16 * t] = acc[t][rr];
     }
   } else if (ptile && t0 == per - 1) {                // (e)
-    form_ptile<STRIP>(Ab + TILE_OFF(k2, k2, nblk), M2buf + (size_t)b * NB * NB, lds, wave, lane, false);
+    form_ptile<STRIP>(Ab + TILE_OFF(k2, k2, nblk), M2, lds, wave, lane, false);
   } else {                                            // (d)
     int I = t0 - (ntri2 + nb2 + 1); if (I >= k2) ++I;
 #pragma unroll
     for (int t = 0; t < NBT; ++t) acc[t] = (v4d){0.0, 0.0, 0.0, 0.0};
-    tile_product<SKIP_LOWER, false, STRIP>(W2 + WT(I), NB, M2buf + (size_t)b * NB * NB, NB, lds, acc, wave, lane);
+    tile_product<SKIP_LOWER, false, STRIP>(W2 + WT(I), NB, M2, NB, lds, acc, wave, lane);
     if (I > k2) {
       double* Ct = Ab + TILE_OFF(I, k2, nblk) + (size_t)(16 * wave + lk) * NB + lr;
 #pragma unroll
@@ -1457,6 +1486,24 @@ k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restr
 }
 
 #undef WT
+
+template <bool STRIP>
+__global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
+k_update2(double* __restrict__ A, int N, int nblk, int k1, const double* __restrict__ Wo1,
+          const double* __restrict__ Wo2, const double* __restrict__ M1buf, const double* __restrict__ M2buf,
+          int total, int ptile) {   // ptile: the pivots left tiles (k1,k1), (k2,k2) to this launch (roles (c'), (e))
+  __shared__ __attribute__((aligned(16))) double lds[STRIP ? S_STAGES * SCH : 4 * DMA_CHUNK];   // strip form: 48 KB, three workgroups per CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int vv = xcd_remap(blockIdx.x, total);
+  const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int v = STRIP ? vv / NBT : vv;
+  const int nb2 = nblk - 2;
+  const int per = nb2 * (nb2 + 1) / 2 + nb2 + 1 + nblk - 1 + ptile;
+  const int b = v / per, t0 = v % per;
+  role_update2<STRIP>(A + (size_t)b * N * N, nblk, k1, Wo1 + (size_t)b * NB * N, Wo2 + (size_t)b * NB * N,
+                      M1buf + (size_t)b * NB * NB, M2buf + (size_t)b * NB * NB, t0, ptile, lds, wave, lane);
+}
+
 
 // ------------------------------------------------------------------ panel
 // grid.x = (nblk-1) * B.  For row block i != k, T = A_ik:  W = T L^-T = T U, stored k-major,
@@ -1495,21 +1542,12 @@ __device__ __forceinline__ void dma_chunk_panel(const double* __restrict__ Tsrc,
   }
 }
 
+// Ab, U, Wob: this GP's matrix, pivot factor and panel; i: the row block (!= k); lds: STRIP ? S_STAGES*SCH : 4*DMA_CHUNK doubles
 template <bool STRIP>
-__global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
-k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Ubuf,
-         double* __restrict__ Wo, int total) {
-  __shared__ __attribute__((aligned(16))) double lds[STRIP ? S_STAGES * SCH : 4 * DMA_CHUNK];   // strip form: 48 KB, three workgroups per CU
-  const int tid = threadIdx.x, lane = tid & 63;
+__device__ __forceinline__ void role_panel(const double* __restrict__ Ab, int nblk, int k, int i,
+                                           const double* __restrict__ U, double* __restrict__ Wob,
+                                           double* __restrict__ lds, int wave, int lane) {
   const int lr = lane & 15, lk = lane >> 4;
-  const int vv = xcd_remap(blockIdx.x, total);
-  const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int v = STRIP ? vv / NBT : vv;
-  const int b = v / (nblk - 1);
-  int i = v % (nblk - 1); if (i >= k) ++i;
-  const double* Ab = A + (size_t)b * N * N;
-  const double* U = Ubuf + (size_t)b * NB * NB;
-  const int i0 = i * NB, k0 = k * NB;
   const bool below = i > k;
   const double* Tsrc = below ? Ab + TILE_OFF(i, k, nblk) : Ab + TILE_OFF(k, i, nblk);
   v4d acc[NBT];
@@ -1521,7 +1559,7 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
   } else {
   dma_chunk_panel(Tsrc, (size_t)NB, below, U, 0, lds, lds + DMA_CHUNK, wave, lane);
   const int r = 16 * wave + lr, rsw = (r >> 1) & 7;
-#pragma unroll
+  CHUNK_LOOP_U
   for (int ch = 0; ch < NB / KC; ++ch) {
     const double* As = lds + (ch & 1) * 2 * DMA_CHUNK;
     const double* Bs = As + DMA_CHUNK;
@@ -1546,11 +1584,25 @@ k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __re
   // same order), so the accumulators hold the k-major panel image itself,
   //   acc[t][rr] = W[r = 16*wave + lr][k' = 16t + lk + 4rr]  ->  Wo[k'][i0 + r],
   // and go out as 128-byte row segments with no transposition through LDS.
-  double* Wt = Wo + (size_t)b * NB * N + (size_t)i * (NB * NB) + 16 * wave + lr;
+  double* Wt = Wob + (size_t)i * (NB * NB) + 16 * wave + lr;
 #pragma unroll
   for (int t = 0; t < NBT; ++t)
 #pragma unroll
     for (int rr = 0; rr < 4; ++rr) Wt[(size_t)(16 * t + lk + 4 * rr) * NB] = acc[t][rr];
+}
+
+template <bool STRIP>
+__global__ void __launch_bounds__(STRIP ? 64 : MM_THREADS, STRIP ? 2 : 4)
+k_panel(const double* __restrict__ A, int N, int nblk, int k, const double* __restrict__ Ubuf,
+         double* __restrict__ Wo, int total) {
+  __shared__ __attribute__((aligned(16))) double lds[STRIP ? S_STAGES * SCH : 4 * DMA_CHUNK];   // strip form: 48 KB, three workgroups per CU
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int vv = xcd_remap(blockIdx.x, total);
+  const int wave = STRIP ? vv % NBT : __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int v = STRIP ? vv / NBT : vv;
+  const int b = v / (nblk - 1);
+  int i = v % (nblk - 1); if (i >= k) ++i;
+  role_panel<STRIP>(A + (size_t)b * N * N, nblk, k, i, Ubuf + (size_t)b * NB * NB, Wo + (size_t)b * NB * N, lds, wave, lane);
 }
 
 // ------------------------------------------------------------------ grad1
@@ -1616,20 +1668,19 @@ k_grad1(const double* __restrict__ A, int N, int n, int nblk, const double* __re
 // grid (nblk, B), 448 threads: same outputs as k_grad1 (alpha, stats1), from the per-tile
 // mat-vec partials the last k_update launch left (grad1_partials) plus the pivot block of
 // that step, the one tile k_update does not own.  Fixed summation order: deterministic.
-__global__ void __launch_bounds__(MM_THREADS)
-k_grad1r(const double* __restrict__ A, int N, int n, int nblk, int k, const double* __restrict__ y,
-         const float* __restrict__ raw, const double* __restrict__ part, int ntri1,
-         double* __restrict__ alpha, double* __restrict__ stats1) {
-  __shared__ double rk[NB];
-  __shared__ double pk[4][NB];
-  __shared__ double pt4[4][NB];
-  __shared__ double red[8 * 4];
-  const int R = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+#define G1R_LDS (NB + 4 * NB + 4 * NB + 32)   // doubles of LDS: rk | pk[4][NB] | pt4[4][NB] | red[32]
+// Role form: row block R of one GP (Ab, yb, rawb, pb = its partials, alphab, stats1b = its outputs); g1s: G1R_LDS doubles
+__device__ __forceinline__ void role_grad1r(const double* __restrict__ Ab, int n, int nblk, int k, int R,
+                                            const double* __restrict__ yb, const float* __restrict__ rawb,
+                                            const double* __restrict__ pb, int ntri1, double* __restrict__ alphab,
+                                            double* __restrict__ stats1b, double* __restrict__ g1s, int tid) {
+  double* rk = g1s;
+  double (*pk)[NB] = (double (*)[NB])(g1s + NB);
+  double (*pt4)[NB] = (double (*)[NB])(g1s + 5 * NB);
+  double* red = g1s + 9 * NB;
+  const int wave = tid >> 6, lane = tid & 63;
   const int per = ntri1 + nblk - 1;
-  const double mean = (double)raw[4 * b + 1];
-  const double* yb = y + (size_t)b * n;
-  const double* Ab = A + (size_t)b * N * N;
-  const double* pb = part + (size_t)b * per * (2 * NB);
+  const double mean = (double)rawb[1];
   if (R == k) {   // pivot block: alpha_k += A_kk r_k  (A_kk symmetric, both triangles stored: read columns, coalesced)
     if (tid < NB) { const int gj = k * NB + tid; rk[tid] = gj < n ? yb[gj] - mean : 0.0; }
     __syncthreads();
@@ -1663,7 +1714,7 @@ k_grad1r(const double* __restrict__ A, int N, int n, int nblk, int k, const doub
     sacc += (pt4[0][tid] + pt4[1][tid]) + (pt4[2][tid] + pt4[3][tid]);
     const int gi = R * NB + tid;
     const double al = gi < n ? -sacc : 0.0;
-    alpha[(size_t)b * N + gi] = al;
+    alphab[gi] = al;
     if (gi < n) {
       const double ri = yb[gi] - mean;
       st[0] = -Ab[TILE_OFF(R, R, nblk) + (size_t)tid * NB + tid];
@@ -1680,7 +1731,19 @@ k_grad1r(const double* __restrict__ A, int N, int n, int nblk, int k, const doub
     }
   }
   __syncthreads();
-  if (tid < 4) stats1[((size_t)b * nblk + R) * 4 + tid] = red[tid] + red[4 + tid];
+  if (tid < 4) stats1b[R * 4 + tid] = red[tid] + red[4 + tid];
+}
+
+
+__global__ void __launch_bounds__(MM_THREADS)
+k_grad1r(const double* __restrict__ A, int N, int n, int nblk, int k, const double* __restrict__ y,
+         const float* __restrict__ raw, const double* __restrict__ part, int ntri1,
+         double* __restrict__ alpha, double* __restrict__ stats1) {
+  __shared__ double g1s[G1R_LDS];
+  const int R = blockIdx.x, b = blockIdx.y;
+  role_grad1r(A + (size_t)b * N * N, n, nblk, k, R, y + (size_t)b * n, raw + 4 * b,
+              part + (size_t)b * (ntri1 + nblk - 1) * (2 * NB), ntri1, alpha + (size_t)b * N, stats1 + (size_t)b * nblk * 4,
+              g1s, threadIdx.x);
 }
 
 // ------------------------------------------------------------------ grad2
@@ -1737,17 +1800,17 @@ __global__ void k_grad2(const double* __restrict__ A, const double* __restrict__
 }
 
 // d == 8 fast path, same thread layout as k_build8 (x_j, alpha_j in registers; x_i, alpha_i LDS broadcasts).
+#define G28_LDS (NB * 8 + NB + 2 * NBT + 2 + 6)   // doubles of LDS: xi | ai | red[2][NBT] | (pad) | hs
+// Role form: tile t = (I,J) of one GP; g2s: G28_LDS doubles (16-byte aligned)
 template <int KID>
-__global__ void __launch_bounds__(MM_THREADS)
-k_grad2_8(const double* __restrict__ A, const double* __restrict__ X, const float* __restrict__ raw,
-          const double* __restrict__ alpha, int n, int N, int ntri, int total, double* __restrict__ stats2) {
-  __shared__ __attribute__((aligned(16))) double xi[NB * 8];
-  __shared__ double ai[NB];
-  __shared__ double red[2][NBT];
-  const int v = xcd_remap(blockIdx.x, total);
-  const int b = v / ntri, t = v % ntri;
-  int I, J; tri_decode(t, I, J);
-  const int tid = threadIdx.x;
+__device__ __forceinline__ void role_grad2_8(const double* __restrict__ Agp, const double* __restrict__ Xb,
+                                             const float* __restrict__ rawb, const double* __restrict__ alphab, int n,
+                                             int N, int I, int J, double* __restrict__ stats2t,
+                                             double* __restrict__ g2s, int tid) {
+  double* xi = g2s;
+  double* ai = g2s + NB * 8;
+  double (*red)[NBT] = (double (*)[NBT])(g2s + NB * 9);
+  double* hs = g2s + NB * 9 + 2 * NBT + 2;
   // diagonal tiles: only the 28 sub-blocks on and below the diagonal (16 threads each, one column per
   // thread); the strictly-lower ones count twice (symmetry), as the off-diagonal tiles do
   const bool sub = (I == J);
@@ -1759,22 +1822,20 @@ k_grad2_8(const double* __restrict__ A, const double* __restrict__ X, const floa
     j = 16 * bj + (tid & 15); i0 = 16 * bi; istep = 1; iend = i0 + 16;
     if (bi != bj) wsym = 2.0;
   }
-  const double* Xb = X + (size_t)b * n * 8;
   const int gj = J * NB + j;
   double xj[8];
 #pragma unroll
   for (int f = 0; f < 8; ++f) xj[f] = gj < n ? Xb[(size_t)gj * 8 + f] : 0.0;
-  const double aj = alpha[(size_t)b * N + gj];
+  const double aj = alphab[gj];
   for (int e = tid; e < NB * 8; e += MM_THREADS) {
     const int gi = I * NB + (e >> 3);
     xi[e] = gi < n ? Xb[(size_t)I * NB * 8 + e] : 0.0;
   }
-  if (tid < NB) ai[tid] = alpha[(size_t)b * N + I * NB + tid];
-  __shared__ double hs[6];
-  load_hyp_shared_put(raw + 4 * b, hs, tid);
+  if (tid < NB) ai[tid] = alphab[I * NB + tid];
+  load_hyp_shared_put(rawb, hs, tid);
   __syncthreads();
   const Hyp h = load_hyp_shared_get(hs);
-  const double* Ab = A + (size_t)b * N * N + TILE_OFF(I, J, N / NB) + j;
+  const double* Ab = Agp + TILE_OFF(I, J, N / NB) + j;
   double s0 = 0.0, s1 = 0.0;
   if (gj < n) {
     const int ireal = min(iend, n - I * NB);   // padding rows contribute nothing
@@ -1800,12 +1861,61 @@ k_grad2_8(const double* __restrict__ A, const double* __restrict__ X, const floa
 #pragma unroll
     for (int w = 0; w < NBT; ++w) s += red[tid][w];
     if (I != J) s *= 2.0;
-    stats2[((size_t)b * ntri + t) * 2 + tid] = s;
+    stats2t[tid] = s;
   }
+}
+
+
+template <int KID>
+__global__ void __launch_bounds__(MM_THREADS)
+k_grad2_8(const double* __restrict__ A, const double* __restrict__ X, const float* __restrict__ raw,
+          const double* __restrict__ alpha, int n, int N, int ntri, int total, double* __restrict__ stats2) {
+  __shared__ __attribute__((aligned(16))) double g2s[G28_LDS];
+  const int v = xcd_remap(blockIdx.x, total);
+  const int b = v / ntri, t = v % ntri;
+  int I, J; tri_decode(t, I, J);
+  role_grad2_8<KID>(A + (size_t)b * N * N, X + (size_t)b * n * 8, raw + 4 * b, alpha + (size_t)b * N, n, N, I, J,
+                    stats2 + ((size_t)b * ntri + t) * 2, g2s, threadIdx.x);
 }
 
 // ------------------------------------------------------------- loss/grad/Adam
 // One thread per GP.  do_step: torch.optim.Adam single-tensor update in float32.
+// One GP: r = its 4 raw parameters, m1 / m2 = its Adam moments, s1 [nblk][4], s2 [ntri][2] = its statistics.
+__device__ __forceinline__ void adam_gp(float* __restrict__ r, float* __restrict__ m1, float* __restrict__ m2,
+                                        const double* __restrict__ s1, const double* __restrict__ s2, double logdet_b,
+                                        int n, int nblk, int ntri, double* __restrict__ loss_b,
+                                        float* __restrict__ grad_b, int do_step, float step_size, float bc2_sqrt,
+                                        float one_minus_b1, float b2, float one_minus_b2, float eps) {
+  double tr = 0.0, aa = 0.0, ar = 0.0, sa = 0.0;
+  for (int I = 0; I < nblk; ++I) {
+    const double* s = s1 + (size_t)I * 4;
+    tr += s[0]; aa += s[1]; ar += s[2]; sa += s[3];
+  }
+  double sk = 0.0, sd = 0.0;
+  for (int t = 0; t < ntri; ++t) { sk += s2[(size_t)t * 2]; sd += s2[(size_t)t * 2 + 1]; }
+  const double os = (double)softplus_f(r[2]);
+  const double dn = (double)n;
+  const double loss = 0.5 * (ar + logdet_b + dn * 1.8378770664093453) / dn;
+  if (loss_b) *loss_b = loss;
+  float g[4];
+  g[0] = (float)(0.5 * (tr - aa) / dn) * sigmoid_f(r[0]);
+  g[1] = (float)(-sa / dn);
+  g[2] = (float)(0.5 * sk / dn) * sigmoid_f(r[2]);
+  g[3] = (float)(0.5 * os * sd / dn) * sigmoid_f(r[3]);
+  if (grad_b) { for (int u = 0; u < 4; ++u) grad_b[u] = g[u]; }
+  if (do_step) {
+    for (int u = 0; u < 4; ++u) {
+      float gu = g[u];
+      float ea = m1[u];
+      ea = ea + one_minus_b1 * (gu - ea);               // lerp_
+      float es = m2[u] * b2 + one_minus_b2 * gu * gu;  // mul_().addcmul_()
+      m1[u] = ea; m2[u] = es;
+      float denom = sqrtf(es) / bc2_sqrt + eps;
+      r[u] = r[u] - step_size * (ea / denom);
+    }
+  }
+}
+
 __global__ void k_adam(float* __restrict__ raw, float* __restrict__ m1, float* __restrict__ m2,
                        const double* __restrict__ stats1, const double* __restrict__ stats2,
                        const double* __restrict__ logdet, int B, int n, int nblk, int ntri,
@@ -1814,34 +1924,198 @@ __global__ void k_adam(float* __restrict__ raw, float* __restrict__ m1, float* _
                        float one_minus_b2, float eps) {
   const int b = blockIdx.x * blockDim.x + threadIdx.x;
   if (b >= B) return;
-  double tr = 0.0, aa = 0.0, ar = 0.0, sa = 0.0;
-  for (int I = 0; I < nblk; ++I) {
-    const double* s = stats1 + ((size_t)b * nblk + I) * 4;
-    tr += s[0]; aa += s[1]; ar += s[2]; sa += s[3];
+  adam_gp(raw + 4 * b, m1 + 4 * b, m2 + 4 * b, stats1 + (size_t)b * nblk * 4, stats2 + (size_t)b * ntri * 2, logdet[b], n,
+          nblk, ntri, loss_out ? loss_out + b : nullptr, grad_out ? grad_out + 4 * b : nullptr, do_step, step_size,
+          bc2_sqrt, one_minus_b1, b2, one_minus_b2, eps);
+}
+
+// ---------------------------------------------------------------- fused per-GP fit (large batches of small matrices)
+// The launch-per-step route above passes the WHOLE batch through HBM a dozen times per evaluation (n = 324: 4.9-6.7 MB of
+// traffic per GP-evaluation against 0.6 MB for the lower triangle itself) and its launches are, one after the other,
+// HBM-bound (build, panel, updates), latency-bound (pivot) or VALU-bound (build, gradient): the chip only ever does one
+// of the three.  Here ONE workgroup owns one GP for its whole fit -- covariance, sweep, alpha, gradient statistics and
+// the Adam step of every iteration, no launch boundary and no inter-workgroup dependence anywhere -- and a persistent
+// grid of two workgroups per CU walks the batch.  The workgroups drift apart in phase, so pivots (latency), tile
+// products (MFMA / L2) and pair loops (VALU) of different GPs overlap on a CU; the matrix, panels and pivot factors live
+// in a per-SLOT workspace (slot = resident workgroup: 512 x 1.9 MB at N = 336 instead of B x 1.9 MB) that the same
+// workgroup re-reads within microseconds of writing it, i.e. out of L2 / Infinity Cache instead of HBM.
+// The body is the sequence of role functions the launch wrappers above execute, on the same data in the same order:
+// results are bit-identical to the launch-per-step route (tests/test_gpu_kernels.py::test_fit_fused_bit_identical).
+// Within a workgroup a role's global stores are ordered before the next role's loads by __syncthreads() (workgroup-
+// scope release / acquire: one CU, one vector L1); nothing the kernel writes is read through a const __restrict__
+// kernel argument, so no read of it can be turned into a scalar load of stale data.
+#define FUSED_MAX_IT 128
+struct AdamTab { float step[FUSED_MAX_IT], bc2s[FUSED_MAX_IT]; };   // per-iteration Adam constants (host doubles -> float, as k_adam gets them)
+struct FusedWs { double *A, *Wo, *Wo2, *U0, *M0, *U1, *M1, *stats1, *stats2, *logdet, *part; };   // [slots][...]
+
+// Out-of-line copies of the roles for the fused kernel: inlined, the compiler hoists every role's lane-invariant address
+// arithmetic to the top of the kernel and keeps it live across all roles (1.4 KB of scratch per lane); as calls each role
+// gets its own register allocation, and a call per 112x112 tile product costs nothing measurable.
+#define FZ __device__ __attribute__((noinline))
+template <int KID>
+FZ void fz_build8(const double* Xb, const float* rawb, double* Agp, int n, int N, int I, int J, double* xi, double* hs) {
+  role_build8<KID>(Xb, rawb, Agp, n, N, I, J, 0, xi, hs, threadIdx.x);
+}
+FZ void fz_pivot(double* Akk, double* Ub, double* Mb, double* logdet_b, int32_t* flags_b, int with_p, double* sm) {
+  role_pivot(Akk, Ub, Mb, logdet_b, flags_b, with_p, sm);
+}
+FZ void fz_panel(const double* Ab, int nblk, int k, int i, const double* U, double* Wob, double* lds) {
+  const int tid = threadIdx.x;
+  role_panel<false>(Ab, nblk, k, i, U, Wob, lds, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+}
+FZ void fz_update(double* Ab, int nblk, int k, const double* Wob, const double* Mb, int ntri1, int t0, int sel, double* lds) {
+  const int tid = threadIdx.x;
+  role_update<false, false>(Ab, nblk, k, Wob, Mb, ntri1, t0, nullptr, nullptr, 0, nullptr, sel, lds, nullptr,
+                            __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, tid);
+}
+FZ void fz_update_last(double* Ab, int nblk, int k, const double* Wob, const double* Mb, int ntri1, int t0, const double* yb,
+                       const float* rawb, int n, double* partb, double* lds, double* rv) {
+  const int tid = threadIdx.x;
+  role_update<true, false>(Ab, nblk, k, Wob, Mb, ntri1, t0, yb, rawb, n, partb, -1, lds, rv,
+                           __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63, tid);
+}
+FZ void fz_update2(double* Ab, int nblk, int k1, const double* W1, const double* W2, const double* M1, const double* M2,
+                   int t0, double* lds) {
+  const int tid = threadIdx.x;
+  role_update2<false>(Ab, nblk, k1, W1, W2, M1, M2, t0, 0, lds, __builtin_amdgcn_readfirstlane(tid >> 6), tid & 63);
+}
+FZ void fz_grad1r(const double* Ab, int n, int nblk, int k, int R, const double* yb, const float* rawb, const double* pb,
+                  int ntri1, double* alphab, double* stats1b, double* g1s) {
+  role_grad1r(Ab, n, nblk, k, R, yb, rawb, pb, ntri1, alphab, stats1b, g1s, threadIdx.x);
+}
+template <int KID>
+FZ void fz_grad2_8(const double* Agp, const double* Xb, const float* rawb, const double* alphab, int n, int N, int I, int J,
+                   double* stats2t, double* g2s) {
+  role_grad2_8<KID>(Agp, Xb, rawb, alphab, n, N, I, J, stats2t, g2s, threadIdx.x);
+}
+#undef FZ
+
+#ifdef GPSR_FUSED_TRACE
+// Debug build only (tools/fused_trace.py): cycles of a fused workgroup by role, summed over evaluations and workgroups:
+// [0] evaluations, [1] covariance, [2] pivots, [3] panels, [4] single-step / restricted updates, [5] two-pivot updates,
+// [6] last update (+ alpha partials), [7] alpha reduce, [8] gradient statistics, [9] whole evaluation
+__device__ unsigned long long g_fused_trace[16];
+#define FTR_T() __builtin_readcyclecounter()
+#define FTR_ADD(i) do { if (tid == 0) { const unsigned long long t_ = FTR_T(); atomicAdd(&g_fused_trace[i], t_ - ftr_t); ftr_t = t_; } } while (0)
+#else
+#define FTR_ADD(i)
+#endif
+
+template <int KID>
+__device__ __forceinline__ void fused_eval(const double* __restrict__ Xb, const double* __restrict__ yb, float* rawb,
+                                           double* alphab, int32_t* flagsb, int n, int N, int nblk, bool with_grad,
+                                           int pair_steps, const FusedWs& s, double* sm, int tid, int wave, int lane) {
+  const int ntri = nblk * (nblk + 1) / 2, ntri1 = (nblk - 1) * nblk / 2;
+#ifdef GPSR_FUSED_TRACE
+  unsigned long long ftr_t = FTR_T();
+  const unsigned long long ftr_t0 = ftr_t;
+#endif
+  double* lds = sm;
+  double* rv = sm + 4 * DMA_CHUNK;
+  for (int t = 0; t < ntri; ++t) {
+    int I, J; tri_decode(t, I, J);
+    fz_build8<KID>(Xb, rawb, s.A, n, N, I, J, sm, sm + NB * 8);
+    __syncthreads();
   }
-  double sk = 0.0, sd = 0.0;
-  for (int t = 0; t < ntri; ++t) { sk += stats2[((size_t)b * ntri + t) * 2]; sd += stats2[((size_t)b * ntri + t) * 2 + 1]; }
-  float* r = raw + 4 * b;
-  const double os = (double)softplus_f(r[2]);
-  const double dn = (double)n;
-  const double loss = 0.5 * (ar + logdet[b] + dn * 1.8378770664093453) / dn;
-  if (loss_out) loss_out[b] = loss;
-  float g[4];
-  g[0] = (float)(0.5 * (tr - aa) / dn) * sigmoid_f(r[0]);
-  g[1] = (float)(-sa / dn);
-  g[2] = (float)(0.5 * sk / dn) * sigmoid_f(r[2]);
-  g[3] = (float)(0.5 * os * sd / dn) * sigmoid_f(r[3]);
-  if (grad_out) { for (int u = 0; u < 4; ++u) grad_out[4 * b + u] = g[u]; }
-  if (do_step) {
-    for (int u = 0; u < 4; ++u) {
-      float gu = g[u];
-      float ea = m1[4 * b + u];
-      ea = ea + one_minus_b1 * (gu - ea);               // lerp_
-      float es = m2[4 * b + u] * b2 + one_minus_b2 * gu * gu;  // mul_().addcmul_()
-      m1[4 * b + u] = ea; m2[4 * b + u] = es;
-      float denom = sqrtf(es) / bc2_sqrt + eps;
-      r[u] = r[u] - step_size * (ea / denom);
+  if (tid == 0) *s.logdet = 0.0;
+  FTR_ADD(1);
+  const int npairs = (pair_steps && nblk >= 3) ? (nblk - 1 - (nblk % 2 == 0 ? 1 : 0)) / 2 : 0;   // as append_sweep_ops
+  const int nb2 = nblk - 2, per2 = nb2 * (nb2 + 1) / 2 + nb2 + 1 + nblk - 1, per1 = ntri1 + nblk - 1;
+  for (int j = 0; j < nblk; ++j) {
+    const bool inpair = j < 2 * npairs, second = inpair && (j & 1), first = inpair && !second, last = j == nblk - 1;
+    double* U = second ? s.U1 : s.U0;
+    double* M = second ? s.M1 : s.M0;
+    double* W = second ? s.Wo2 : s.Wo;
+    fz_pivot(s.A + TILE_OFF(j, j, nblk), U, M, s.logdet, flagsb, last ? 2 : 1, sm);
+    __syncthreads();
+    FTR_ADD(2);
+    for (int q = 0; q < nblk - 1; ++q) {
+      fz_panel(s.A, nblk, j, q + (q >= j ? 1 : 0), U, W, lds);
+      __syncthreads();
     }
+    FTR_ADD(3);
+    if (second) {
+      for (int t0 = 0; t0 < per2; ++t0) {
+        fz_update2(s.A, nblk, j - 1, s.Wo, s.Wo2, s.M0, s.M1, t0, lds);
+        __syncthreads();
+      }
+      FTR_ADD(5);
+    } else if (!first && last) {
+      for (int t0 = 0; t0 < per1; ++t0) {
+        fz_update_last(s.A, nblk, j, W, M, ntri1, t0, yb, rawb, n, s.part, lds, rv);
+        __syncthreads();
+      }
+      FTR_ADD(6);
+    } else {
+      const int sel = first ? j + 1 : -1, cnt = first ? nblk : per1;
+      for (int t0 = 0; t0 < cnt; ++t0) {
+        fz_update(s.A, nblk, j, W, M, ntri1, t0, sel, lds);
+        __syncthreads();
+      }
+      FTR_ADD(4);
+    }
+  }
+  for (int R = 0; R < nblk; ++R) {
+    fz_grad1r(s.A, n, nblk, nblk - 1, R, yb, rawb, s.part, ntri1, alphab, s.stats1, sm);
+    __syncthreads();
+  }
+  FTR_ADD(7);
+  if (with_grad) {
+    for (int t = 0; t < ntri; ++t) {
+      int I, J; tri_decode(t, I, J);
+      fz_grad2_8<KID>(s.A, Xb, rawb, alphab, n, N, I, J, s.stats2 + 2 * t, sm);
+      __syncthreads();
+    }
+  }
+  FTR_ADD(8);
+#ifdef GPSR_FUSED_TRACE
+  if (tid == 0) { atomicAdd(&g_fused_trace[0], 1ull); atomicAdd(&g_fused_trace[9], FTR_T() - ftr_t0); }
+#endif
+}
+
+// grid = slots (<= 2 per CU), 448 threads, dynamic LDS = PIVOT_LDS_BYTES.  Iterations it0 .. it0+nit-1 (0-based) of the
+// Adam loop, then (final_eval) the evaluation at the final hyper-parameters that leaves alpha.  nblk >= 2, d == 8.
+template <int KID>
+__global__ void __launch_bounds__(MM_THREADS, 4)
+k_fit_fused(const double* __restrict__ X, const double* __restrict__ y, float* raw, double* alpha, double* loss,
+            int32_t* flags, float* m1g, float* m2g, int B, int n, int N, int nit, int final_eval, AdamTab tab,
+            FusedWs w, int pair_steps, int stagger, float one_minus_b1, float b2, float one_minus_b2, float eps) {
+  extern __shared__ __attribute__((aligned(16))) double fsm[];
+  __shared__ float mom[8];
+  const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const int nblk = N / NB, ntri = nblk * (nblk + 1) / 2, ntri1 = (nblk - 1) * nblk / 2;
+  const int slot = blockIdx.x;
+  FusedWs s;
+  s.A = w.A + (size_t)slot * N * N;
+  s.Wo = w.Wo + (size_t)slot * NB * N;
+  s.Wo2 = w.Wo2 + (size_t)slot * NB * N;
+  s.U0 = w.U0 + (size_t)slot * NB * NB; s.M0 = w.M0 + (size_t)slot * NB * NB;
+  s.U1 = w.U1 + (size_t)slot * NB * NB; s.M1 = w.M1 + (size_t)slot * NB * NB;
+  s.stats1 = w.stats1 + (size_t)slot * nblk * 4;
+  s.stats2 = w.stats2 + (size_t)slot * ntri * 2;
+  s.logdet = w.logdet + slot;
+  s.part = w.part + (size_t)slot * (ntri1 + nblk - 1) * (2 * NB);
+  // the two workgroups of a CU would otherwise run in lock step (same phase = same bottleneck at the same time):
+  // the second half of the grid starts `stagger` x ~3.4 us late
+  if (blockIdx.x >= (gridDim.x + 1) / 2)
+    for (int i = 0; i < stagger; ++i) __builtin_amdgcn_s_sleep(127);
+  for (int b = blockIdx.x; b < B; b += gridDim.x) {
+    const double* Xb = X + (size_t)b * n * 8;
+    const double* yb = y + (size_t)b * n;
+    float* rawb = raw + 4 * (size_t)b;
+    double* alphab = alpha + (size_t)b * N;
+    if (tid < 4) { mom[tid] = m1g[4 * (size_t)b + tid]; mom[4 + tid] = m2g[4 * (size_t)b + tid]; }
+    __syncthreads();
+    for (int e = 0; e < nit + final_eval; ++e) {
+      const bool with_grad = e < nit;
+      fused_eval<KID>(Xb, yb, rawb, alphab, flags + b, n, N, nblk, with_grad, pair_steps, s, fsm, tid, wave, lane);
+      if (with_grad && tid == 0)
+        adam_gp(rawb, mom, mom + 4, s.stats1, s.stats2, *s.logdet, n, nblk, ntri, loss ? loss + b : nullptr, nullptr, 1,
+                tab.step[e], tab.bc2s[e], one_minus_b1, b2, one_minus_b2, eps);
+      __syncthreads();
+    }
+    if (tid < 4) { m1g[4 * (size_t)b + tid] = mom[tid]; m2g[4 * (size_t)b + tid] = mom[4 + tid]; }
+    __syncthreads();
   }
 }
 

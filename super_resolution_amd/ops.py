@@ -153,6 +153,11 @@ def set_split_small(on):
     return bool(_lib.load().gpsr_set_split_small(1 if on else 0))
 
 
+def set_fused(on):
+    """gpsr_set_fused: the one-launch per-GP route of gpsr_fit (opt-in, bit-identical, measured slower). Returns the previous setting."""
+    return bool(_lib.load().gpsr_set_fused(1 if on else 0))
+
+
 def loss_grad(X, y, kernel_id, raw, workspace=None):
     lib = _lib.load()
     B, n, d = X.shape
@@ -386,7 +391,7 @@ def active_sample(data, K, n_pick, bandwidth, w_rep, w_div):
 
 
 # ------------------------------------------------------------ kernel timing
-PROF_TAGS = ("update", "panel", "pivot", "build", "grad1", "grad2", "predict", "update_last", "update2", "update_sel")
+PROF_TAGS = ("update", "panel", "pivot", "build", "grad1", "grad2", "predict", "update_last", "update2", "update_sel", "fused")
 
 
 def profile_begin(max_records=65536):

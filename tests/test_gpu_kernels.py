@@ -353,6 +353,33 @@ def test_fit_split_small_bit_identical(B, n):
     assert int(outs[0][2].sum()) == 0
 
 
+@pytest.mark.parametrize("B,n,kid,iters", [(37, 324, 2, 3), (9, 196, 0, 4), (5, 784, 3, 2), (1100, 324, 3, 2),
+                                           (3, 196, 1, 131), (6, 500, 4, 2)])
+def test_fit_fused_bit_identical(B, n, kid, iters):
+    """gpsr_set_fused (opt-in): ONE launch per fit, one workgroup per GP running the role functions of the
+    launch-per-step route back to back (k_fit_fused) -- the same bits: 2-, 3-, 5- and 7-block matrices, all five
+    kernels, more GPs than resident workgroup slots (1100 > 512: a slot's workspace is reused), more iterations than
+    one launch's table of Adam constants holds (131 > 128: the moments continue across launches)."""
+    from super_resolution_amd import ops
+    rng = np.random.default_rng(B + n)
+    X = to_dev(rng.random((B, n, 8)))
+    y = to_dev(rng.random((B, n)))
+    raw0 = ops.init_hypers(y, kid)
+    outs = []
+    for fused in (False, True):
+        prev = ops.set_fused(fused)
+        try:
+            raw = raw0.clone()
+            alpha, flags, loss = ops.fit(X, y, kid, raw, iters=iters, want_loss=True)
+            torch.cuda.synchronize()
+            outs.append((alpha.clone(), raw.clone(), flags.clone(), loss.clone()))
+        finally:
+            ops.set_fused(prev)
+    for name, u, v in zip(("alpha", "raw", "flags", "loss"), outs[0], outs[1]):
+        assert torch.equal(u, v), (name, int((u != v).sum()))
+    assert int(outs[0][2].sum()) == 0
+
+
 def test_context_workspace_and_flag_count():
     """gpsr_create / gpsr_destroy: the library-owned workspace gives the same fit as a caller-owned one;
     gpsr_flag_count is the synchronising read-out of the per-GP failure flags."""
