@@ -129,15 +129,19 @@ class AGPRSuperResolution:
 
     def upscale(self, image: np.ndarray) -> np.ndarray:
         # the colour image goes to the GPU once: conversion, chroma resize and merge are HIP kernels (agpr.py:148-158)
-        bgr = torch.as_tensor(np.ascontiguousarray(image, dtype=np.uint8)).to(_device())
+        return self.upscale_device(torch.as_tensor(np.ascontiguousarray(image, dtype=np.uint8)).to(_device())).cpu().numpy()
+
+    def upscale_device(self, bgr):
+        """uint8 BGR device image -> device result of upscale() (agpr.py:148-158): uint8 BGR in YCrCb mode, float64
+        grey * 255 in GRAYSCALE mode."""
         if COLOR_SPACE == ColorSpace.YCRCB:
             y, cr, cb = ops.bgr2ycrcb(bgr)
             y = ops.unit_to_u8(self.upscale_channel_device(ops.u8_to_unit(y)), 1.0)     # .astype(np.uint8), agpr.py:151
             cr = imgproc.resize_cubic_u8_dev(cr, dsize=(y.shape[1], y.shape[0]))
             cb = imgproc.resize_cubic_u8_dev(cb, dsize=(y.shape[1], y.shape[0]))
-            return ops.ycrcb2bgr(y, cr, cb).cpu().numpy()
+            return ops.ycrcb2bgr(y, cr, cb)
         elif COLOR_SPACE == ColorSpace.GRAYSCALE:
-            return self.upscale_channel_device(ops.u8_to_unit(ops.bgr2gray(bgr))).cpu().numpy()
+            return self.upscale_channel_device(ops.u8_to_unit(ops.bgr2gray(bgr)))
 
     def upscale_channel(self, image: np.ndarray) -> np.ndarray:
         return self.upscale_channel_device(_to_dev(image / 255.)).cpu().numpy()

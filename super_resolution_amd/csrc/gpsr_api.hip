@@ -524,11 +524,18 @@ static SideStream* side_stream() {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
   SideStream* ss = &g_side[dev];
-  if (!ss->ok) {
+  if (!ss->ok) {   // all three or nothing: what was created is destroyed again if a later creation fails
     if (hipStreamCreateWithFlags(&ss->s, hipStreamNonBlocking) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-    if (hipEventCreateWithFlags(&ss->join, hipEventDisableTiming) != hipSuccess) return nullptr;
-    ss->ok = true;
+    if (hipEventCreateWithFlags(&ss->fork, hipEventDisableTiming) != hipSuccess) {
+      (void)hipStreamDestroy(ss->s);
+      return nullptr;
+    }
+    if (hipEventCreateWithFlags(&ss->join, hipEventDisableTiming) != hipSuccess) {
+      (void)hipEventDestroy(ss->fork);
+      (void)hipStreamDestroy(ss->s);
+      return nullptr;
+    }
+    ss->ok = true;   // lives until the thread's process ends (one side stream per thread and device)
   }
   return ss;
 }
@@ -543,21 +550,23 @@ static int run_dual(const std::vector<Op>& ops, const Batch& a, Batch b, const F
   // the host feeds the two streams alternately, one big launch (and the small ones before it) at a time
   const size_t n = ops.size();
   size_t ia = 0, ib = 0;
-  while (ia < n || ib < n) {
-    while (ia < n) {
+  while (!rc && (ia < n || ib < n)) {
+    while (!rc && ia < n) {
       const Op& op = ops[ia++];
-      if ((rc = launch_op(op, a, c))) return rc;
+      rc = launch_op(op, a, c);
       if (op.heavy) break;
     }
-    while (ib < n) {
+    while (!rc && ib < n) {
       const Op& op = ops[ib++];
-      if ((rc = launch_op(op, b, c))) return rc;
+      rc = launch_op(op, b, c);
       if (op.heavy) break;
     }
   }
-  if ((e = hipEventRecord(ss->join, b.st)) != hipSuccess) return hip_fail(e, "join record");
-  if ((e = hipStreamWaitEvent(a.st, ss->join, 0)) != hipSuccess) return hip_fail(e, "join wait");
-  return 0;
+  // also after a failed launch: the side stream may still be working on the caller's buffers, so the caller's stream
+  // must not run (or free) past this call before it has drained -- and a capture must not be left forked
+  if ((e = hipEventRecord(ss->join, b.st)) != hipSuccess) return rc ? rc : hip_fail(e, "join record");
+  if ((e = hipStreamWaitEvent(a.st, ss->join, 0)) != hipSuccess) return rc ? rc : hip_fail(e, "join wait");
+  return rc;
 }
 
 // Default schedule of a large batch: the launches that fill the chip (covariance, the big updates, the gradient pass)
@@ -620,12 +629,15 @@ static int run_split_small(const std::vector<Op>& ops, const Batch& full, const 
     if ((e = hipEventRecord(ss->fork, full.st)) != hipSuccess) return hip_fail(e, "fork record");
     if ((e = hipStreamWaitEvent(b.st, ss->fork, 0)) != hipSuccess) return hip_fail(e, "fork wait");
     // op by op, first half then second half: the host alternates, the two streams drain side by side
-    for (size_t t = i; t < j; ++t) {
-      if ((rc = launch_op(ops[t], a, c))) return rc;
-      if ((rc = launch_op(ops[t], b, c))) return rc;
+    for (size_t t = i; t < j && !rc; ++t) {
+      rc = launch_op(ops[t], a, c);
+      if (!rc) rc = launch_op(ops[t], b, c);
     }
-    if ((e = hipEventRecord(ss->join, b.st)) != hipSuccess) return hip_fail(e, "join record");
-    if ((e = hipStreamWaitEvent(full.st, ss->join, 0)) != hipSuccess) return hip_fail(e, "join wait");
+    // the join is recorded and waited for even when a launch failed: the side stream may hold work on the caller's
+    // workspace, and a stream capture must not be left with an unjoined fork
+    if ((e = hipEventRecord(ss->join, b.st)) != hipSuccess) return rc ? rc : hip_fail(e, "join record");
+    if ((e = hipStreamWaitEvent(full.st, ss->join, 0)) != hipSuccess) return rc ? rc : hip_fail(e, "join wait");
+    if (rc) return rc;
     i = j;
   }
   return 0;
@@ -784,10 +796,24 @@ static void* g_noalloc_ptr[64] = {};
 #include <mutex>
 static std::mutex g_noalloc_mu;
 
-static int noalloc_scratch(void** out) {
+// The array the kernels of this call must use is the copy on the device the STREAM belongs to (the launches go
+// there), which need not be the thread's current device: a non-null stream is asked for its device, and a stream of
+// another device than the current one is refused (hipGetSymbolAddress answers for the current device only, and the
+// launch itself would fail).  The null stream is the current device's.
+static int noalloc_scratch(hipStream_t st, void** out) {
   int dev = -1;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return hip_fail(e, "hipGetDevice");
+  if (st) {
+    hipDevice_t sdev = -1;
+    e = hipStreamGetDevice(st, &sdev);
+    if (e != hipSuccess) return hip_fail(e, "hipStreamGetDevice");
+    if ((int)sdev != dev) {
+      snprintf(g_err, sizeof(g_err), "gpsr_fit_noalloc: the stream belongs to device %d, the current device is %d "
+               "(hipSetDevice to the stream's device first)", (int)sdev, dev);
+      return -1;
+    }
+  }
   if (dev < 0 || dev >= 64) return arg_fail("device index out of range for the static scratch table");
   std::lock_guard<std::mutex> lock(g_noalloc_mu);
   if (!g_noalloc_ptr[dev]) {
@@ -817,9 +843,9 @@ extern "C" int gpsr_fit_noalloc(const double* X, const double* y, int B, int n, 
     return -1;
   }
   void* ws = nullptr;
-  int rc = noalloc_scratch(&ws);
-  if (rc) return rc;
   hipStream_t st = (hipStream_t)stream;
+  int rc = noalloc_scratch(st, &ws);
+  if (rc) return rc;
   hipError_t e = hipMemsetAsync(flags, 0, (size_t)B * 4, st);
   if (e != hipSuccess) return hip_fail(e, "memset flags");
   Batch a = {};

@@ -33,13 +33,44 @@ def deal_chains(lens, world):
     return owner
 
 
+# Diagnostics of the exchange (bench.py --gpus N prints them per rank, so that a scaling run explains itself): number
+# of calls, bytes this rank contributed / received, and -- on CUDA tensors -- HIP events around the collective.
+STATS = {"calls": 0, "bytes_sent": 0, "bytes_received": 0, "rows_owned": 0, "events": []}
+
+
+def reset_stats():
+    STATS.update(calls=0, bytes_sent=0, bytes_received=0, rows_owned=0, events=[])
+
+
+def stats_summary():
+    """-> dict with the counters and the total milliseconds inside the collectives (synchronises on their events)."""
+    ms = 0.0
+    for a, b in STATS["events"]:
+        b.synchronize()
+        ms += a.elapsed_time(b)
+    return {"exchange_calls": STATS["calls"], "bytes_sent": STATS["bytes_sent"], "bytes_received": STATS["bytes_received"],
+            "rows_owned": STATS["rows_owned"], "exchange_ms": round(ms, 3)}
+
+
+def _as_range(idx):
+    """(lo, hi) if the index array is the contiguous range lo..hi-1, else None."""
+    n = len(idx)
+    if n == 0:
+        return (0, 0)
+    lo = int(idx[0])
+    return (lo, lo + n) if int(idx[-1]) == lo + n - 1 and (n < 3 or np.array_equal(idx, np.arange(lo, lo + n))) else None
+
+
 def exchange_rows(locals_, owned, B, rank, world, group=None, force_collective=False):
     """The one collective of the path.  Every rank holds, for each tensor of `locals_`, the rows it computed
     (row i of the local tensor = global row owned[rank][i]); returns the full [B, ...] tensors on every rank.
     The row payloads of all tensors are packed byte-wise into one buffer of max-rows-per-rank rows, exchanged
     with a single all_gather_into_tensor (RCCL all-gather over xGMI; no list API, no per-tensor collectives)
-    and scattered to their global rows.  owned: list over ranks of int64 index arrays (known to every rank).
-    A rank that owns nothing sends an all-padding buffer.  force_collective: also for world == 1 (RCCL smoke)."""
+    and scattered to their global rows: a rank's rows go to their place with one strided copy per tensor when the rank
+    owns a contiguous range (independent GPs: always), with an index_copy_ otherwise (whole chains dealt out).
+    owned: list over ranks of int64 index arrays (known to every rank).  A rank that owns nothing sends padding
+    (the padding rows of the buffer are never read, so the buffer is not cleared).
+    force_collective: also for world == 1 (RCCL smoke)."""
     cnt = len(owned[rank])
     for t in locals_:
         assert t.shape[0] == cnt, (t.shape, cnt)
@@ -50,31 +81,50 @@ def exchange_rows(locals_, owned, B, rank, world, group=None, force_collective=F
             o.index_copy_(0, torch.as_tensor(owned[0]).to(t.device), t)
             outs.append(o)
         return outs
+    dst_all = np.concatenate([np.asarray(o, dtype=np.int64) for o in owned])
+    assert dst_all.size == B and np.array_equal(np.sort(dst_all), np.arange(B)), "every global row must have exactly one owner"
     dev = locals_[0].device
     cap = max(1, max(len(o) for o in owned))
     widths = [int(np_prod(t.shape[1:])) * t.element_size() for t in locals_]
     row_bytes = (sum(widths) + 15) // 16 * 16
-    buf = torch.zeros((cap, row_bytes), dtype=torch.uint8, device=dev)
+    buf = torch.empty((cap, row_bytes), dtype=torch.uint8, device=dev)
     col = 0
     for t, w in zip(locals_, widths):
         if cnt:
             buf[:cnt, col:col + w] = t.contiguous().view(cnt, -1).view(torch.uint8).view(cnt, w)
         col += w
     out = torch.empty((world * cap, row_bytes), dtype=torch.uint8, device=dev)
+    ev = None
+    if buf.is_cuda:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     if dist.get_backend(group) == "gloo" and buf.is_cuda:   # one-GPU rehearsal: gloo moves host memory
         hout = torch.empty(out.shape, dtype=torch.uint8)
         dist.all_gather_into_tensor(hout, buf.cpu(), group=group)
         out = hout.to(dev)
     else:
         dist.all_gather_into_tensor(out, buf, group=group)
-    src = np.concatenate([r * cap + np.arange(len(o), dtype=np.int64) for r, o in enumerate(owned)])
-    dst = np.concatenate([np.asarray(o, dtype=np.int64) for o in owned])
-    assert dst.size == B and np.array_equal(np.sort(dst), np.arange(B)), "every global row must have exactly one owner"
-    perm = torch.as_tensor(src[np.argsort(dst)]).to(dev)
-    rows = out.index_select(0, perm)                       # [B, row_bytes] in global row order
+    if ev is not None:
+        ev[1].record()
+        STATS["events"].append(ev)
+    STATS["calls"] += 1
+    STATS["bytes_sent"] += cap * row_bytes
+    STATS["bytes_received"] += world * cap * row_bytes
+    STATS["rows_owned"] += cnt
     outs, col = [], 0
     for t, w in zip(locals_, widths):
-        outs.append(rows[:, col:col + w].contiguous().view(t.dtype).view((B,) + tuple(t.shape[1:])))
+        full = torch.empty((B, w), dtype=torch.uint8, device=dev)
+        for r, o in enumerate(owned):
+            k = len(o)
+            if k == 0:
+                continue
+            src = out[r * cap:r * cap + k, col:col + w]
+            rng = _as_range(np.asarray(o))
+            if rng is not None:
+                full[rng[0]:rng[1]] = src
+            else:
+                full.index_copy_(0, torch.as_tensor(np.asarray(o, dtype=np.int64)).to(dev), src.contiguous())
+        outs.append(full.view(t.dtype).view((B,) + tuple(t.shape[1:])))
         col += w
     return outs
 

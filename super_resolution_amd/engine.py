@@ -142,23 +142,28 @@ class BatchedGP:
         idx_all = torch.as_tensor(np.asarray(flat, dtype=np.int64)).to(dev)
         order_t = torch.as_tensor(np.asarray(order, dtype=np.int64)).to(dev)
         cur = carry.index_select(0, order_t).contiguous()      # [nch,4] in `order`
-        ws = self._workspace(min(nch, B), n, d, dev)
-        alpha_all = torch.empty((B, ops.padded_n(n)), dtype=torch.float64, device=dev)
-        pos = 0
+        # the chains of a link are independent GPs: more of them than the workspace budget holds (many images per
+        # call) run in groups, like fit_predict's chunks
+        bc = self.chunk_size(nch, n, d)
+        ws = self._workspace(min(nch, bc), n, d, dev)
+        alpha_all = torch.empty((B, ops.padded_n(n)), dtype=torch.float64, device=dev)   # 8 N bytes per GP: X / Xs, which
+        pos = 0                                                                        # the caller holds, are 64 (n + m)
         for k, bk in enumerate(steps):
-            idx = idx_all[pos:pos + bk]
+            for g0 in range(0, bk, bc):
+                g1 = min(bk, g0 + bc)
+                idx = idx_all[pos + g0:pos + g1]
+                Xk, yk = X.index_select(0, idx), y.index_select(0, idx)
+                r = ops.init_hypers(yk, self.kernel_id, carry=cur[g0:g1])
+                alpha, fl = ops.fit(Xk, yk, self.kernel_id, r, self.iters, self.lr, ws)
+                alpha_all.index_copy_(0, idx, alpha)
+                raw.index_copy_(0, idx, r)
+                flags.index_copy_(0, idx, fl)
+                cur[g0:g1] = r
             pos += bk
-            Xk, yk = X.index_select(0, idx), y.index_select(0, idx)
-            r = ops.init_hypers(yk, self.kernel_id, carry=cur[:bk])
-            alpha, fl = ops.fit(Xk, yk, self.kernel_id, r, self.iters, self.lr, ws)
-            alpha_all.index_copy_(0, idx, alpha)
-            raw.index_copy_(0, idx, r)
-            flags.index_copy_(0, idx, fl)
-            cur[:bk] = r
-        carry.index_copy_(0, order_t, cur)
         # the predictive means do not feed the chain: one batched launch for all links at the end (the mean of a GP
         # depends on its own X, alpha and hyper-parameters only), instead of one small launch per link
         pred = ops.predict(X, Xs, alpha_all, raw, self.kernel_id)
+        carry.index_copy_(0, order_t, cur)
         return pred, raw, flags
 
 
@@ -216,23 +221,21 @@ def predict_pixels_batch(jobs, s, p, gp, stride_percentage=0.9, use_all_pixels=T
                  for jl in job_lists]
         my_jobs = job_lists[rank]
     mine = owned[rank]
-    # gather this rank's patches, job by job
-    Xl, yl, Xsl = [], [], []
+    # gather this rank's patches, job by job, straight into the batch buffers (one allocation, no concatenation pass)
+    nmine = int(mine.size)
+    X = torch.empty((nmine, n, 8), dtype=torch.float64, device=dev)   # a rank without work (fewer patches / chains than
+    y = torch.empty((nmine, n), dtype=torch.float64, device=dev)      # ranks) still takes part in the exchange: 0 rows
+    Xs = torch.empty((nmine, m, 8), dtype=torch.float64, device=dev)
+    pos = 0
     for j, ((tin, ttg, tst), (H, W, rows, cols, locs)) in enumerate(zip(jobs, geo)):
         sel = mine[(mine >= offs[j]) & (mine < offs[j + 1])] - offs[j]
         if sel.size:
             assert tin is not None and tst is not None, f"job {j}: this rank owns patches of an image it was not given"
-            X, y, Xs = ops.gather(tin, ttg, tst, s, p, torch.as_tensor(np.ascontiguousarray(locs[sel])).to(dev), tidx)
-            Xl.append(X); yl.append(y); Xsl.append(Xs)
-    if Xl:
-        X = torch.cat(Xl) if len(Xl) > 1 else Xl[0]
-        y = torch.cat(yl) if len(yl) > 1 else yl[0]
-        Xs = torch.cat(Xsl) if len(Xsl) > 1 else Xsl[0]
-    else:   # a rank without work (fewer patches / chains than ranks) still takes part in the exchange
-        X = torch.empty((0, n, 8), dtype=torch.float64, device=dev)
-        y = torch.empty((0, n), dtype=torch.float64, device=dev)
-        Xs = torch.empty((0, m, 8), dtype=torch.float64, device=dev)
-    del Xl, yl, Xsl
+            k = int(sel.size)
+            ops.gather(tin, ttg, tst, s, p, torch.as_tensor(np.ascontiguousarray(locs[sel])).to(dev), tidx,
+                       out=(X[pos:pos + k], y[pos:pos + k], Xs[pos:pos + k]))
+            pos += k
+    assert pos == nmine
     if chain_carry is None:
         if X.shape[0]:
             pred, raw, flags = gp.fit_predict(X, y, Xs)

@@ -88,20 +88,52 @@ def _imwrite(path, bgr):
     Image.fromarray(np.ascontiguousarray(bgr[:, :, ::-1])).save(path)
 
 
+class _Tally:
+    """Running PSNR / SSIM sums per label; averages on demand (labels keep their first-seen order)."""
+
+    def __init__(self):
+        self.sums = {}
+
+    def add(self, label, score):
+        if score.number_of_images:
+            p, q, k = self.sums.get(label, (0.0, 0.0, 0))
+            self.sums[label] = (p + score.psnr, q + score.ssim, k + score.number_of_images)
+
+    def mean(self, label):
+        p, q, k = self.sums.get(label, (0.0, 0.0, 0))
+        return PerceptualSimilarity(p / k, q / k, 1) if k else PerceptualSimilarity(0, 0, 0)
+
+
+# the rows of the reference's per-image comparison (evaluation.py:100-115): label -> where the image comes from
+_FILE_ROWS = (("Bicubic (Baseline)", "bicubic", True), ("AGPR", "AGPR", False))
+_FILE_LABELS = frozenset(r[0] for r in _FILE_ROWS)
+_KERNEL_ROWS = (rbf_kernel, exponential_kernel, matern32_kernel, matern52_kernel, spectral_mixture_kernel, linear_kernel)
+
+
 class Evaluator:
     def __init__(self, srf, image_nums=range(1, 15), verbose=False, generate_gpr_images=False, dataset_dir="Set14"):
         self.srf = srf
         self.image_nums = image_nums
         self.verbose = verbose
-        self.metrics = defaultdict(lambda: PerceptualSimilarity(0, 0, 0))
         self.generate_gpr_images = generate_gpr_images
         self.dataset_dir = dataset_dir
+        self.clear()
 
     def clear(self):
+        self._tally = _Tally()
         self.metrics = defaultdict(lambda: PerceptualSimilarity(0, 0, 0))
 
+    # ------------------------------------------------------------------ files
     def _path(self, i, method):
         return f'{self.dataset_dir}/image_SRF_{self.srf}/img_{i:03d}_SRF_{self.srf}_{method}.png'
+
+    def get_image(self, i, method, fail_on_nonexistent=False):
+        path = self._path(i, method)
+        if os.path.exists(path):
+            return _imread(path)
+        if fail_on_nonexistent:
+            raise Exception(f'Image {path} does not exist')
+        return None
 
     def get_hr_image(self, i):
         return self.get_image(i, 'HR', fail_on_nonexistent=True)
@@ -113,39 +145,30 @@ class Evaluator:
         return self.get_image(i, 'AGPR')
 
     def get_gpr_image(self, i, kernel):
-        kernel_name = get_kernel_name(kernel)
-        image = self.get_image(i, f'GPR_{kernel_name}')
+        """The stored GPR_<kernel> output; with generate_gpr_images a missing one is produced (and stored) first."""
+        tag = f'GPR_{get_kernel_name(kernel)}'
+        image = self.get_image(i, tag)
         if image is None and self.generate_gpr_images:
             from .gprsr import GPRSR, USED_COLOR_SPACE
             image = GPRSR(self.srf, kernel, USED_COLOR_SPACE).apply(_imread(self._path(i, 'LR')))
-            _imwrite(self._path(i, f'GPR_{kernel_name}'), image)
+            _imwrite(self._path(i, tag), image)
         return image
 
-    def get_image(self, i, method, fail_on_nonexistent=False):
-        path = self._path(i, method)
-        if not os.path.exists(path):
-            if fail_on_nonexistent:
-                raise Exception(f'Image {path} does not exist')
-            return None
-        return _imread(path)
+    # ------------------------------------------------------------------ metrics (evaluation.py:70-98)
+    def preprocess_image(self, image):
+        if len(image.shape) == 3:
+            image = imgproc.bgr2gray(image)
+        return image[self.srf:-self.srf, self.srf:-self.srf]
 
-    def get_metrics(self, hr_image, upsampled_image, name):
-        if upsampled_image is None:
-            return PerceptualSimilarity(0, 0, 0)
-        psnr, ssim = self._metrics_gpu(hr_image, upsampled_image)
-        if self.verbose:
-            print(f'{name} - PSNR: {psnr:.3f}, SSIM: {ssim:.3f}')
-        return PerceptualSimilarity(psnr, ssim)
+    def _prepared(self, hr_image, upsampled_image, preprocess):
+        return (self.preprocess_image(hr_image), self.preprocess_image(upsampled_image)) if preprocess \
+            else (hr_image, upsampled_image)
 
     def get_psnr(self, hr_image, upsampled_image, preprocess=False):
-        if preprocess:
-            hr_image, upsampled_image = self.preprocess_image(hr_image), self.preprocess_image(upsampled_image)
-        return peak_signal_noise_ratio(hr_image, upsampled_image, data_range=255)
+        return peak_signal_noise_ratio(*self._prepared(hr_image, upsampled_image, preprocess), data_range=255)
 
     def get_ssim(self, hr_image, upsampled_image, preprocess=False):
-        if preprocess:
-            hr_image, upsampled_image = self.preprocess_image(hr_image), self.preprocess_image(upsampled_image)
-        return structural_similarity(hr_image, upsampled_image, data_range=255)
+        return structural_similarity(*self._prepared(hr_image, upsampled_image, preprocess), data_range=255)
 
     def _metrics_gpu(self, hr_image, upsampled_image):
         """PSNR and SSIM of two images as read from disk (BGR or grey uint8): grey conversion, crop by srf and both
@@ -160,49 +183,56 @@ class Evaluator:
         m = ops.metrics(grey(hr_image), grey(upsampled_image), self.srf).cpu().numpy()
         return float(m[0]), float(m[1])
 
-    def preprocess_image(self, image):
-        if len(image.shape) == 3:
-            image = imgproc.bgr2gray(image)
-        return image[self.srf:-self.srf, self.srf:-self.srf]
+    def get_metrics(self, hr_image, upsampled_image, name):
+        if upsampled_image is None:
+            return PerceptualSimilarity(0, 0, 0)
+        score = PerceptualSimilarity(*self._metrics_gpu(hr_image, upsampled_image))
+        if self.verbose:
+            print(f'{name} - PSNR: {score.psnr:.3f}, SSIM: {score.ssim:.3f}')
+        return score
+
+    # ------------------------------------------------------------------ aggregation
+    def _rows_of(self, i):
+        """(label, image or None) for every method the per-image comparison lists."""
+        for label, tag, required in _FILE_ROWS:
+            yield label, self.get_image(i, tag, fail_on_nonexistent=required)
+        for kernel in _KERNEL_ROWS:
+            label = get_kernel_name(kernel)
+            fittable = getattr(kernel, "kernel_id", None) is not None   # spectral mixture: stored outputs only
+            yield label, (self.get_gpr_image(i, kernel) if fittable or not self.generate_gpr_images
+                          else self.get_image(i, f'GPR_{label}'))
 
     def evaluate_image(self, i):
         if self.verbose:
             print(f'Image {i}')
         hr_image = self.get_hr_image(i)
-        self.metrics['Bicubic (Baseline)'] += self.get_metrics(hr_image, self.get_bicubic_image(i), 'Bicubic (Baseline)')
-        self.metrics['AGPR'] += self.get_metrics(hr_image, self.get_agpr_image(i), 'AGPR')
-        for kernel in [rbf_kernel, exponential_kernel, matern32_kernel, matern52_kernel, spectral_mixture_kernel,
-                       linear_kernel]:
-            name = get_kernel_name(kernel)
-            img = self.get_gpr_image(i, kernel) if (not self.generate_gpr_images or getattr(kernel, "kernel_id", None)
-                                                    is not None) else self.get_image(i, f'GPR_{name}')
-            if img is not None:
-                self.metrics[name] += self.get_metrics(hr_image, img, name)
+        for label, image in self._rows_of(i):
+            if image is None and label not in _FILE_LABELS:   # a kernel without a stored output has no row
+                continue
+            score = self.get_metrics(hr_image, image, label)
+            self._tally.add(label, score)
+            self.metrics[label] += score
 
     def evaluate_method(self, method, metric=PerceptualSimilarityMetric.ALL):
-        kernel_name = get_kernel_name(method) if _is_kernel(method) else method
+        by_kernel = _is_kernel(method)
+        label = get_kernel_name(method) if by_kernel else method
         if self.verbose:
-            print(f'Method {kernel_name}')
-        result = PerceptualSimilarity(0, 0, 0)
+            print(f'Method {label}')
+        tally = _Tally()
         for i in self.image_nums:
-            hr_image = self.get_hr_image(i)
-            up = self.get_gpr_image(i, method) if _is_kernel(method) else self.get_image(i, method)
-            result += self.get_metrics(hr_image, up, kernel_name)
-        result = result.average()
+            image = self.get_gpr_image(i, method) if by_kernel else self.get_image(i, method)
+            tally.add(label, self.get_metrics(self.get_hr_image(i), image, label))
+        result = tally.mean(label)
         if self.verbose:
             print(f'Average - PSNR: {result.psnr:.3f}, SSIM: {result.ssim:.3f}', flush=True)
-        if metric == PerceptualSimilarityMetric.PSNR:
-            return result.psnr
-        elif metric == PerceptualSimilarityMetric.SSIM:
-            return result.ssim
-        return result
+        return {PerceptualSimilarityMetric.PSNR: result.psnr, PerceptualSimilarityMetric.SSIM: result.ssim}.get(metric, result)
 
     def evaluate(self):
         for i in self.image_nums:
             self.evaluate_image(i)
-        for key, value in self.metrics.items():
-            self.metrics[key] = value.average()
+        for label in list(self.metrics):
+            self.metrics[label] = self._tally.mean(label)
         print('Averages')
-        for key, value in self.metrics.items():
-            print(f'{key} - PSNR: {value.psnr:.3f}, SSIM: {value.ssim:.3f}')
+        for label, value in self.metrics.items():
+            print(f'{label} - PSNR: {value.psnr:.3f}, SSIM: {value.ssim:.3f}')
         return self.metrics

@@ -72,13 +72,17 @@ class GPRSR:
     For RBF the three coincide."""
 
     def __init__(self, scaling_factor, used_kernel=matern52_kernel, color_mode=ColorSpace.YUV, *,
-                 warm_start="chain", iters=50, shard=None, max_workspace_bytes=48 << 30, outputs="all"):
+                 warm_start="chain", iters=50, shard=None, max_workspace_bytes=48 << 30, outputs="all",
+                 patch_size=None):
         assert warm_start in ("independent", "chain", "chain_per_image")
         assert outputs in ("all", "owned")
         # outputs (sharded runs only): "all" = every rank returns every HR image; "owned" = a rank returns the
         # images it fitted patches of and None for the others (data-parallel deployments, bench.py's weak scaling:
         # the ranks then skip recombination and image stages of each other's images in both phases)
         self.outputs = outputs
+        # patch_size: LR patch edge instead of the reference's int(10 * s) (gprsr.py:132) -- an engine knob for larger
+        # GPs (p = 34 -> n = 1024, bench.py --workload p34); None = the reference's rule
+        self.patch_size = patch_size
         self.scaling_factor = scaling_factor
         self.current_scaling_factor = None
         self.used_kernel = used_kernel
@@ -203,11 +207,14 @@ class GPRSR:
         assert float(s) == int(s), "the patch pipeline needs an integer step factor (2 or 3)"
         return int(s)
 
+    def _p(self):
+        return int(self.patch_size) if self.patch_size is not None else int(self.current_scaling_factor * 10)
+
     def _upsample(self, imgs, recombine="all"):
         s = self.current_scaling_factor
         own = [True] * len(imgs)
         if recombine == "owned" and self.shard is not None:   # the bicubic image of another rank's image is never read
-            own = engine.owned_jobs([tuple(im.shape) for im in imgs], int(s * 10), STRIDE_PERCENTAGE, self.shard,
+            own = engine.owned_jobs([tuple(im.shape) for im in imgs], self._p(), STRIDE_PERCENTAGE, self.shard,
                                     self._carry is not None)
         bic = [imgproc.resize_cubic(im, fx=s, fy=s) if o else None for im, o in zip(imgs, own)]
         return self._predict_pixels(list(zip(imgs, imgs, bic)), recombine=recombine)
@@ -218,8 +225,9 @@ class GPRSR:
 
     def _predict_pixels(self, jobs, recombine="all"):
         s = self._s_int()
-        p = int(self.current_scaling_factor * 10)
+        p = self._p()
         mode = PATCH_INTERPOLATION.value
+        self._gp.lr = LEARNING_RATE     # the reference reads the constant per patch (gprsr.py:178): read per call, not at construction
         return engine.predict_pixels_batch(jobs, s, p, self._gp, STRIDE_PERCENTAGE, USE_ALL_PIXELS_FOR_TRAINING,
                                            mode, chain_carry=self._carry, stats=self.stats, shard=self.shard,
                                            recombine=recombine if self.shard is not None else "all")

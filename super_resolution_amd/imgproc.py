@@ -218,8 +218,21 @@ def resize_cubic_u8(img, fx=None, fy=None, dsize=None):
     xi, xw = _axis_tables_u8(Wd, W)
     yi, yw = _axis_tables_u8(Hd, H)
 
-    def fma(a, b, c):   # float32 fused multiply-add: the float32 product is exact in float64
-        return (a.astype(np.float64) * b.astype(np.float64) + c.astype(np.float64)).astype(np.float32)
+    def fma(a, b, c):
+        """float32 fused multiply-add, exactly: the product of two float32 is exact in float64; the sum is taken in float64
+        ROUNDED TO ODD (TwoSum gives the rounding error; an inexact even result moves to its odd neighbour on the side of the
+        error), and a round-to-odd 53-bit value converts to float32 with the one rounding of a true fmaf -- a plain float64
+        sum followed by the conversion rounds twice and can land on the other side of a float32 tie."""
+        p = a.astype(np.float64) * b.astype(np.float64)
+        c = np.broadcast_to(np.asarray(c, dtype=np.float64), np.broadcast(p, c).shape)
+        p = np.broadcast_to(p, c.shape)
+        s = p + c
+        bb = s - p
+        err = (p - (s - bb)) + (c - bb)
+        even = (s.view(np.int64) & 1) == 0
+        toward = np.where(err > 0, np.inf, -np.inf)
+        s = np.where((err != 0) & even, np.nextafter(s, toward), s)
+        return s.astype(np.float32)
     src = img.astype(np.float32)
     t = [src[:, xi[:, k]] for k in range(4)]
     w = [xw[None, :, k] for k in range(4)]

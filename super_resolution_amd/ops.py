@@ -52,19 +52,26 @@ def unblock(Ab):
     return Ab.view(B, nb, nb, BLOCK, BLOCK).permute(0, 1, 3, 2, 4).contiguous().view(B, N, N)
 
 
-def gather(train_in, train_tgt, test_in, s, p, locs, tidx):
-    """-> X [B,n,8], y [B,n], Xs [B,m,8]   (gpsr_gather)."""
+def gather(train_in, train_tgt, test_in, s, p, locs, tidx, out=None):
+    """-> X [B,n,8], y [B,n], Xs [B,m,8]   (gpsr_gather).  out = (X, y, Xs): write into these (contiguous row slices of
+    a batch buffer) instead of allocating."""
     lib = _lib.load()
     H, W = train_in.shape
     B, nt = locs.shape[0], tidx.shape[0]
     n, m = nt * nt, (p * s - 2) ** 2
     dev = train_in.device
-    X = torch.empty((B, n, 8), dtype=torch.float64, device=dev)
-    y = torch.empty((B, n), dtype=torch.float64, device=dev)
-    Xs = torch.empty((B, m, 8), dtype=torch.float64, device=dev)
+    if out is None:
+        X = torch.empty((B, n, 8), dtype=torch.float64, device=dev)
+        y = torch.empty((B, n), dtype=torch.float64, device=dev)
+        Xs = torch.empty((B, m, 8), dtype=torch.float64, device=dev)
+    else:
+        X, y, Xs = out
+        if X.shape != (B, n, 8) or y.shape != (B, n) or Xs.shape != (B, m, 8):
+            raise _lib.GpsrError(f"gather: out shapes {tuple(X.shape)}, {tuple(y.shape)}, {tuple(Xs.shape)} do not fit B={B}, n={n}, m={m}")
     _lib.check(lib.gpsr_gather(_p(train_in, torch.float64), _p(train_tgt, torch.float64),
                                _p(test_in, torch.float64), H, W, s, p, _p(locs, torch.int32), B,
-                               _p(tidx, torch.int32), nt, _p(X), _p(y), _p(Xs), _stream()), "gpsr_gather")
+                               _p(tidx, torch.int32), nt, _p(X, torch.float64), _p(y, torch.float64),
+                               _p(Xs, torch.float64), _stream()), "gpsr_gather")
     return X, y, Xs
 
 

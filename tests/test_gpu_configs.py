@@ -1,6 +1,7 @@
 """GPU tests at the size of the BASELINE.json configurations that no other test reaches:
   config 4  synthetic 3840x2160 LR x2, Matern-3/2: 32 400 patches at full size, the engine's workspace chunking
-  config 3  a BSD100-shaped batch (100 images of 160x107, x3) sharded over two ranks
+  config 3  BSD100-shaped batches (100 images of 160x107 at x3 and of 240x160 at x2) sharded over two ranks
+  config 1  one Set14 image_SRF_2 image, x2, RBF, GRAYSCALE, through main.py
   config 5  "n ~ 1k": p = 34 -> n = 1024 training points per GP (10 pivot blocks)
 Full-size checks use properties + sampled patches against the oracle (the oracle needs ~0.5 s per n=324 fit)."""
 import os
@@ -71,32 +72,37 @@ from bench import synthetic_lr
 rank, world, local = gdist.init_from_env()
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
-imgs = [ops.u8_to_unit(torch.as_tensor(synthetic_lr(107, 160, seed)).to(dev)) for seed in range(100)]   # BSD100 HR 321x481 / 3
-for mode in ("independent", "chain_per_image"):
-    g = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start=mode, shard=(rank, world))
-    sharded = g.apply_for_channel_device(imgs)
-    assert g.stats.raw[0].shape == (3500, 4) and all(int(f.sum()) == 0 for f in g.stats.flags)
-    if rank == 0:
-        whole = GPRSR(3, K.matern52_kernel, ColorSpace.GRAYSCALE, warm_start=mode).apply_for_channel_device(imgs)
-        assert all(torch.equal(a, b) for a, b in zip(sharded, whole)), mode + ": sharded != unsharded"
-        assert all(o.shape == (321, 480) and bool(torch.isfinite(o).all()) for o in whole)
-        sys.stdout.write(mode + "-ok\n")
-    dist.barrier()
+# BSD100 HR is 321x481: LR 107x160 at x3 (35 patches per image, n = 784), 160x240 at x2 (150 patches per image, n = 324)
+for s, (H, W), per in ((3, (107, 160), 35), (2, (160, 240), 150)):
+    imgs = [ops.u8_to_unit(torch.as_tensor(synthetic_lr(H, W, seed)).to(dev)) for seed in range(100)]
+    kern = K.matern52_kernel if s == 3 else K.matern32_kernel
+    for mode in ("independent", "chain_per_image"):
+        g = GPRSR(s, kern, ColorSpace.GRAYSCALE, warm_start=mode, shard=(rank, world))
+        sharded = g.apply_for_channel_device(imgs)
+        assert g.stats.raw[0].shape == (100 * per, 4) and all(int(f.sum()) == 0 for f in g.stats.flags)
+        if rank == 0:
+            whole = GPRSR(s, kern, ColorSpace.GRAYSCALE, warm_start=mode).apply_for_channel_device(imgs)
+            assert all(torch.equal(a, b) for a, b in zip(sharded, whole)), mode + ": sharded != unsharded"
+            assert all(o.shape == (H * s, W * s) and bool(torch.isfinite(o).all()) for o in whole)
+            sys.stdout.write("x%%d-%%s-ok\n" %% (s, mode))
+        dist.barrier()
+    del imgs, sharded
 dist.destroy_process_group()
 """
 
 
 def test_bsd100_shaped_batch_two_ranks(tmp_path):
-    """BASELINE config 3 rehearsed on the one GPU of the box: 100 images of 160x107 x3 (3 500 patches, 7 000 fits of
-    n = 784) over two ranks -- patches sharded (independent) and whole chains dealt out (chain_per_image) -- equal
-    the one-rank result to the bit.  Collectives ride on gloo here (RCCL refuses two ranks on one device)."""
+    """BASELINE config 3 ("BSD100 x2 and x3") rehearsed on the one GPU of the box: 100 generated images of BSD100's LR
+    shape at x3 (160x107: 3 500 patches, 7 000 fits of n = 784) AND at x2 (240x160: 15 000 patches, 30 000 fits of
+    n = 324) over two ranks -- patches sharded (independent) and whole chains dealt out (chain_per_image) -- equal the
+    one-rank result to the bit.  Collectives ride on gloo here (RCCL refuses two ranks on one device)."""
     script = tmp_path / "child.py"
     script.write_text(CHILD % (ROOT, ROOT))
     env = dict(os.environ, GPSR_LOCAL_DEVICE="0", GPSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", "29641", str(script)],
                        capture_output=True, text=True, timeout=900, env=env)
-    assert r.returncode == 0 and "independent-ok" in r.stdout and "chain_per_image-ok" in r.stdout, \
+    assert r.returncode == 0 and all(f"x{s}-{m}-ok" in r.stdout for s in (3, 2) for m in ("independent", "chain_per_image")), \
         r.stdout[-2000:] + r.stderr[-3000:]
 
 
@@ -125,3 +131,33 @@ def test_n1024_fit_predict_vs_oracle(kid):
         mean, rawo = ogp.fit_predict_patch(Xo, yo, Xso, kid)
         assert np.allclose(raw[k].cpu().numpy(), rawo, rtol=2e-3, atol=2e-3), (raw[k].cpu().numpy(), rawo)
         assert np.abs(pred[k] - mean).max() < 1e-4
+
+
+def test_config1_set14_x2_rbf_through_main(golden_dir, tmp_path, capsys):
+    """BASELINE config 1 as written: `python main.py --srf 2 --kernel rbf --color-space grayscale --images 1` on the
+    reference's Set14/image_SRF_2/img_001_SRF_2_LR.png (fixture refpin/x2_lr_001.png): 240 patches, 480 fits of n = 324,
+    RBF re-initialised per patch (gprsr.py:167-172: no chain, the warm-start modes coincide).  The written
+    img_001_SRF_2_GPR_RBF_gray.png must be the CPU oracle's output (refpin/oracle_x2_rbf_gray_001.png,
+    tests/golden/make_config1_golden.py) to one grey level, PSNR / SSIM against the HR image within 0.01 dB / 0.001."""
+    import shutil
+    from PIL import Image
+    import main
+    src = os.path.join(golden_dir, "refpin")
+    dst = tmp_path / "Set14" / "image_SRF_2"
+    dst.mkdir(parents=True)
+    shutil.copy(f"{src}/x2_lr_001.png", dst / "img_001_SRF_2_LR.png")
+    shutil.copy(f"{src}/x2_hr_001.png", dst / "img_001_SRF_2_HR.png")
+    rc = main.main(["--srf", "2", "--kernel", "rbf", "--color-space", "grayscale", "--images", "1",
+                    "--dataset-dir", str(tmp_path / "Set14"), "--evaluate"])
+    assert rc == 0
+    out = capsys.readouterr().out
+    assert "Average - PSNR:" in out and "Upscaling took" in out
+    got = np.array(Image.open(dst / "img_001_SRF_2_GPR_RBF_gray.png"))
+    want = np.array(Image.open(f"{src}/oracle_x2_rbf_gray_001.png"))
+    hr = np.array(Image.open(f"{src}/x2_hr_001.png"))
+    assert got.shape == want.shape + (3,) and np.array_equal(got[..., 0], got[..., 1]) and np.array_equal(got[..., 0], got[..., 2])
+    d = np.abs(got[..., 0].astype(int) - want.astype(int))
+    assert d.max() <= 1 and (d == 0).mean() > 0.999, (d.max(), (d == 0).mean())
+    c = 2
+    assert abs(cvops.psnr(hr[c:-c, c:-c], got[c:-c, c:-c, 0]) - cvops.psnr(hr[c:-c, c:-c], want[c:-c, c:-c])) <= 0.01
+    assert abs(cvops.ssim(hr[c:-c, c:-c], got[c:-c, c:-c, 0]) - cvops.ssim(hr[c:-c, c:-c], want[c:-c, c:-c])) <= 0.001

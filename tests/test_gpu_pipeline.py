@@ -217,13 +217,13 @@ def test_set14_x3_chain_per_image_vs_oracle_chain_goldens(golden_dir):
         assert abs(cvops.ssim(hr[c:-c, c:-c], got[c:-c, c:-c]) - cvops.ssim(hr[c:-c, c:-c], want[c:-c, c:-c])) <= 0.001
     assert min(ident) > 0.999, ident
     assert all(int(f.sum()) == 0 for f in g.stats.flags)
-    # the reference's own committed img_001_SRF_3_GPR_matern52.png IS this run (chained, first image of a fresh process:
-    # tests/test_gpu_refpin.py reproduces it on every pixel from the colour LR file).  Here the input is the grey fixture
-    # lr_001.png, which round 1 made with the 14-bit grey table (0.14 % of its pixels are one level off the 15-bit
-    # BGR2GRAY the reference applies), so the agreement stops at 99.4 %, max 1 level -- a loose pin only
+    # the reference's own committed img_001_SRF_3_GPR_matern52.png IS this run (chained, first image of a fresh process)
+    # and lr_001.png is exactly what gprsr.py:53,91 feeds it (15-bit BGR2GRAY of the reference's LR file): the oracle's
+    # golden equals that PNG bit for bit (tests/test_refpin.py), the HIP output to the truncating cast's last level
     ref = load("refout_m52_001.png")
+    assert np.array_equal(load("oracle_m52_chain_001.png"), ref)
     dd = np.abs(outs[0].astype(int) - ref.astype(int))
-    assert dd.max() <= 1 and (dd == 0).mean() > 0.99
+    assert dd.max() <= 1 and (dd == 0).mean() > 0.9999, (dd.max(), (dd == 0).mean())
 
 
 @pytest.mark.parametrize("kid,s,chunk", [(3, 2, 0), (0, 3, 3), (2, 2, 4)])

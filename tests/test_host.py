@@ -223,11 +223,14 @@ rank, world, _ = gdist.init_from_env("gloo")
 # Stand-ins for the device ops (no GPU here): gather = real patch features in numpy,
 # the "GP" = a deterministic function of each patch, combine = oracle recombination.
 from oracle import patches as P
-def fake_gather(tin, ttg, tst, s, p, locs, tidx):
+def fake_gather(tin, ttg, tst, s, p, locs, tidx, out=None):
     tin, ttg, tst = tin.numpy(), ttg.numpy(), tst.numpy()
     X = np.stack([P.features(P.extract(tin, l, p, 1)) for l in locs.numpy()])
     y = np.stack([P.targets(P.extract(ttg, l, p, 1)) for l in locs.numpy()])
     Xs = np.stack([P.features(P.extract(tst, l, p, s)) for l in locs.numpy()])
+    if out is not None:   # the engine gathers straight into slices of its batch buffers
+        out[0].copy_(torch.tensor(X)); out[1].copy_(torch.tensor(y)); out[2].copy_(torch.tensor(Xs))
+        return out
     return torch.tensor(X), torch.tensor(y), torch.tensor(Xs)
 def fake_combine(pred, tst, H, W, s, p, rows, cols, mode, clip=True):
     locs = [(int(r), int(c)) for r in rows for c in cols]

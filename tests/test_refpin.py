@@ -79,6 +79,19 @@ def test_oracle_reproduces_the_references_x3_outputs(golden_dir, kid, tag):
     assert ident >= 0.999 and maxd <= 1
 
 
+def test_headline_fixtures_are_the_references_inputs_and_its_output(golden_dir):
+    """The headline workload's inputs are exactly what gprsr.py:53,91 feeds the path -- lr_XXX.png = the 15-bit
+    cv.cvtColor(BGR2GRAY) of the reference's LR file (the colour copy refpin/x3_lr_001.png converts to lr_001.png bit for
+    bit) -- and the committed oracle output of the chained mode for img_001 (480 Matern-5/2 fits of n = 784, made by
+    tests/golden/make_set14_chain_goldens.py from lr_001.png) IS the reference's own img_001_SRF_3_GPR_matern52.png
+    (refout_m52_001.png): every pixel.  No fit runs here: both sides are committed files."""
+    from PIL import Image
+    d = os.path.join(golden_dir, "set14_x3")
+    lr = np.array(Image.open(f"{d}/lr_001.png"))
+    assert np.array_equal(cvops.bgr2gray(_bgr(_load(golden_dir, "x3_lr_001.png"))), lr)
+    assert np.array_equal(np.array(Image.open(f"{d}/oracle_m52_chain_001.png")), np.array(Image.open(f"{d}/refout_m52_001.png")))
+
+
 # ---------------------------------------------------------------- the reference's COLOUR outputs (YUV mode)
 def _explained_by_chroma(ref_bgr, U, V):
     """Share of pixels whose reference BGR value is yuv2bgr(Y, U, V) for SOME luma Y: a test of the colour stages and

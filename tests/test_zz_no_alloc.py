@@ -18,13 +18,22 @@ def _fit_both(lib, ops, X, y, kid, iters):
     alpha_b = torch.full((B, N), float("nan"), dtype=torch.float64, device=X.device)
     loss_b = torch.full((B,), float("nan"), dtype=torch.float64, device=X.device)
     flags_b = torch.full((B,), -1, dtype=torch.int32, device=X.device)
-    before = torch.cuda.memory_allocated()
     st = torch.cuda.current_stream().cuda_stream
-    rc = lib.gpsr_fit_noalloc(X.data_ptr(), y.data_ptr(), B, n, d, kid, raw_b.data_ptr(), iters, 0.1,
-                              alpha_b.data_ptr(), loss_b.data_ptr(), flags_b.data_ptr(), st)
+    raw_w = raw_b.clone()
+    call = lambda r: lib.gpsr_fit_noalloc(X.data_ptr(), y.data_ptr(), B, n, d, kid, r.data_ptr(), iters, 0.1,
+                                          alpha_b.data_ptr(), loss_b.data_ptr(), flags_b.data_ptr(), st)
+    # "allocates nothing" at the DRIVER level: torch.cuda.memory_allocated() only sees torch's caching allocator and
+    # would miss a hipMalloc inside libgpsr.so, so compare hipMemGetInfo's free bytes around a call -- the second one
+    # of this shape (the first may make the runtime size its per-kernel scratch pool, which no caller can avoid)
+    assert call(raw_w) == 0, lib.gpsr_last_error()
+    torch.cuda.synchronize()
+    free_before = torch.cuda.mem_get_info()[0]
+    before = torch.cuda.memory_allocated()
+    rc = call(raw_b)
     assert rc == 0, lib.gpsr_last_error()
     torch.cuda.synchronize()
     assert torch.cuda.memory_allocated() == before
+    assert torch.cuda.mem_get_info()[0] == free_before, "gpsr_fit_noalloc changed the device's free memory"
     assert torch.equal(alpha_a, alpha_b), (alpha_a - alpha_b).abs().max()
     assert torch.equal(raw_a, raw_b) and torch.equal(loss_a, loss_b)
     assert torch.equal(flags_a, flags_b) and int(flags_b.sum()) == 0
