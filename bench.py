@@ -292,6 +292,10 @@ def main(argv=None):
     ap.add_argument("--warm-start", default="independent", choices=("independent", "chain_per_image", "chain"))
     ap.add_argument("--synthetic", action="store_true", help="synthetic images of the Set14 shapes instead of the fixtures")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--profile-all", action="store_true",
+                    help="bracket every tagged launch inside the timed region (default: only the dominant kernel; the other "
+                         "kernels' milliseconds then come from one extra untimed step)")
+    ap.add_argument("--no-kernel-breakdown", action="store_true", help="skip that extra untimed step")
     ap.add_argument("--no-reference-check", action="store_true",
                     help="skip the untimed runs against the reference's own PNGs (parity.*vs_reference_png): under rocprofv3 "
                          "their launches would enter the per-kernel averages of the profile")
@@ -368,14 +372,33 @@ def main(argv=None):
         step()
     barrier()
     gdist.reset_stats()
-    if rank == 0:
-        ops.profile_begin(1 << 18)
+    # HIP-event brackets inside the timed region around the launches of the kernel the roofline object describes only
+    # (two event records per bracketed launch: bracketing all 188 000 launches of a chained Set14 x3 step costs a
+    # quarter of it, bracketing all 2 600 of an independent step < 1 %); --profile-all brackets every tagged launch
+    nblk_w = -(-((p_edge or 10 * s) - 2) ** 2 // NB)
+    dom_tags = ["update2"] if nblk_w >= 3 else ["update", "update_last"]
+    chained = a.warm_start != "independent" and kname != "rbf"
+    live = a.profile_all or not chained      # chained modes: no brackets at all in the timed region (see the roofline note)
+    if rank == 0 and live:
+        ops.profile_begin(1 << 18, tags=None if a.profile_all else dom_tags)
     t0 = time.perf_counter()
     for _ in range(a.steps):
         outs = step()
     barrier()
     dt = time.perf_counter() - t0
-    prof = ops.profile_end() if rank == 0 else None
+    prof = ops.profile_end() if (rank == 0 and live) else None
+    prof_all = None
+    if rank == 0 and not a.profile_all and not a.no_kernel_breakdown and world == 1:
+        # per-kernel milliseconds of ONE more step, untimed, every tagged launch bracketed (roofline.kernel_ms_per_step)
+        ops.profile_begin(1 << 18)
+        step()
+        torch.cuda.synchronize()
+        prof_all = ops.profile_end()
+    steps_prof = a.steps
+    if rank == 0 and prof is None:
+        if prof_all is None:
+            raise SystemExit("chained modes take the roofline from the extra profiled step: drop --no-kernel-breakdown")
+        prof, steps_prof = prof_all, 1
     ranks_seen, backend = 1, None
     if world > 1:
         backend = torch.distributed.get_backend()
@@ -472,11 +495,12 @@ def main(argv=None):
     # 51 evaluations per step, however the engine cut the batch (workspace chunks, chain links, dual-stream halves)
     passes = ((nblk - 1) // 2 if nblk % 2 else (nblk - 2) // 2) if kname_dom == "k_update2" else nblk
     B_local = -(-n_patches // world)
-    gps_per_launch = B_local * (2 * (g.iters + 1) * passes * a.steps) / cnt if cnt else 0.0
+    gps_per_launch = B_local * (2 * (g.iters + 1) * passes * steps_prof) / cnt if cnt else 0.0
     flops_launch = int(gps_per_launch * flops_gp)
     avg_s = (ms / cnt) * 1e-3 if cnt else float("nan")
     achieved = flops_launch / avg_s / 1e12 if cnt else float("nan")
-    kernel_ms = {k: round(v[1] / a.steps, 3) for k, v in prof.items()}
+    kernel_ms = ({k: round(v[1] / steps_prof, 3) for k, v in prof.items()} if a.profile_all
+                 else {k: round(v[1], 3) for k, v in prof_all.items()} if prof_all else None)
     traffic, traffic_src = pmc_traffic(kname_dom, int(round(gps_per_launch)), N)
     whole = (n_patches / world) * 2 * fit_flops(n, m, g.iters) / (dt / a.steps) / 1e12    # per GPU
     roofline = {"kernel": kname_dom, "bound": "mfma", "achieved": round(achieved, 3),
@@ -486,9 +510,15 @@ def main(argv=None):
                 else "no committed PMC summary for this shape",
                 "whole_step_frac": round(whole / FP64_MFMA_PEAK_TFLOPS, 4),
                 "whole_step_note": "SURVEY 8(d) algorithmic flops of all fits of one GPU / step time / FP64 peak",
-                "launches_per_step": cnt // max(1, a.steps), "gps_per_launch": round(gps_per_launch, 1),
+                "launches_per_step": cnt // max(1, steps_prof), "gps_per_launch": round(gps_per_launch, 1),
+                "measured": "HIP events on the launch stream inside the timed region" if live else
+                            "HIP events in one extra step after the timed region: a chained step is ~190 000 small launches and "
+                            "two event records per launch would cost a quarter of the time it is meant to measure",
                 "avg_launch_ms": round(avg_s * 1e3, 4),
-                "flops_per_launch": flops_launch, "kernel_ms_per_step": kernel_ms}
+                "flops_per_launch": flops_launch, "kernel_ms_per_step": kernel_ms,
+                "kernel_ms_note": "every tagged launch bracketed inside the timed region" if a.profile_all else
+                                  "from one extra untimed step with every tagged launch bracketed (the timed region brackets "
+                                  "only the dominant kernel)"}
 
     cpu = cpu1 = None
     if not a.no_cpu_baseline and world == 1:   # reported at N=1 only (rank 0 would stall the other ranks' exit)

@@ -376,6 +376,7 @@ enum {
   GPSR_PROF_FUSED,       /* k_fit_fused: a whole fit (<= 128 Adam iterations + the final evaluation) of the batch */
   GPSR_PROFILE_NTAGS
 };
+int gpsr_profile_select(unsigned tag_mask);   /* bit t set: launches with tag t are bracketed (default: all tags) */
 int gpsr_profile_begin(int max_records);
 int gpsr_profile_end(int32_t* counts, double* total_ms);
 

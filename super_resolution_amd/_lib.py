@@ -54,6 +54,7 @@ SIGNATURES = {
     "gpsr_agpr_weights": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "gpsr_agpr_filter": (c_int, [c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_void_p]),
     "gpsr_selftest_mfma": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p]),
+    "gpsr_profile_select": (c_int, [ctypes.c_uint]),
     "gpsr_profile_begin": (c_int, [c_int]),
     "gpsr_profile_end": (c_int, [c_void_p, c_void_p]),
     "gpsr_u8_to_unit": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p]),

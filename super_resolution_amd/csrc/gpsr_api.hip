@@ -36,14 +36,23 @@ static std::vector<ProfRec> g_prof;
 static size_t g_prof_used = 0;
 static bool g_prof_on = false;
 
+static unsigned g_prof_mask = ~0u;   // tags that are bracketed (gpsr_profile_select)
 static inline ProfRec* prof_start(int tag, hipStream_t st) {
-  if (!g_prof_on || g_prof_used >= g_prof.size()) return nullptr;
+  if (!g_prof_on || !((g_prof_mask >> tag) & 1u) || g_prof_used >= g_prof.size()) return nullptr;
   ProfRec* r = &g_prof[g_prof_used++];
   r->tag = tag;
   (void)hipEventRecord(r->a, st);
   return r;
 }
 static inline void prof_stop(ProfRec* r, hipStream_t st) { if (r) (void)hipEventRecord(r->b, st); }
+
+// Which tags gpsr_profile_begin brackets (bit t = tag t; default all).  Two hipEventRecord per launch are not free: on
+// the chained warm-start modes (188 000 small launches per Set14 x3 step) bracketing every launch costs a quarter of
+// the step, so bench.py brackets only the kernel its roofline object describes inside the timed region.
+extern "C" int gpsr_profile_select(unsigned tag_mask) {
+  g_prof_mask = tag_mask;
+  return 0;
+}
 
 extern "C" int gpsr_profile_begin(int max_records) {
   if (max_records < 1 || max_records > (1 << 20)) return arg_fail("max_records");

@@ -401,8 +401,12 @@ def active_sample(data, K, n_pick, bandwidth, w_rep, w_div):
 PROF_TAGS = ("update", "panel", "pivot", "build", "grad1", "grad2", "predict", "update_last", "update2", "update_sel", "fused")
 
 
-def profile_begin(max_records=65536):
-    _lib.check(_lib.load().gpsr_profile_begin(int(max_records)), "gpsr_profile_begin")
+def profile_begin(max_records=65536, tags=None):
+    """tags: names out of PROF_TAGS to bracket (None: all).  Two event records per bracketed launch."""
+    lib = _lib.load()
+    mask = 0xFFFFFFFF if tags is None else sum(1 << PROF_TAGS.index(t) for t in tags)
+    _lib.check(lib.gpsr_profile_select(mask), "gpsr_profile_select")
+    _lib.check(lib.gpsr_profile_begin(int(max_records)), "gpsr_profile_begin")
 
 
 def profile_end():
