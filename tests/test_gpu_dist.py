@@ -128,3 +128,25 @@ def test_two_ranks_on_one_gpu_chained_mode_equals_one_rank(tmp_path):
                         "--master-addr", "127.0.0.1", "--master-port", "29633", str(script)],
                        capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "chain-shard-ok" in r.stdout, r.stdout[-2000:] + r.stderr[-8000:]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("workload,scaling", [("tiny", "weak"), ("tiny", "strong")])
+def test_bench_two_ranks_on_one_gpu_prints_the_line_and_the_per_rank_account(workload, scaling):
+    """`bench.py --gpus 2` as the driver's scaling run starts it (its own launcher, one process per rank), rehearsed on
+    the one GPU of the box with gloo collectives: rank 0 prints ONE JSON line for n_gpus = 2 with the per-rank account
+    of the exchange (GP fits per step, bytes into the all-gather, milliseconds inside it)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    env.update(GPSR_LOCAL_DEVICE="0", GPSR_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", workload, "--scaling", scaling,
+                        "--steps", "1", "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, env=env, timeout=600)
+    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-3000:]
+    line = json.loads(r.stdout.strip().splitlines()[-1])
+    assert line["n_gpus"] == 2 and line["scaling"] == scaling and line["value"] > 0
+    assert line["config"]["ranks_in_process_group"] == 2 and line["config"]["backend"] == "gloo"
+    ranks = line["ranks"]
+    assert [q["rank"] for q in ranks] == [0, 1]
+    n_fits = int(line["config"]["workload"].split(" GP fits")[0].split(", ")[-1])
+    assert sum(q["gp_fits_per_step"] for q in ranks) == n_fits           # every fit on exactly one rank
+    assert all(q["exchange_calls"] == 2 and q["allgather_bytes_sent_per_pass"] > 0 and q["exchange_ms_per_step"] > 0 for q in ranks)

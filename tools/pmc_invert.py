@@ -24,6 +24,19 @@ if mode == "eval":
     torch.cuda.synchronize()
     print("flags", int(flags.sum()), "loss0", float(loss[0]))
     sys.exit(0)
+if mode == "fit1":
+    # one Adam iteration + the final evaluation (two evaluations per GP) through gpsr_fit: the route GPSR_FUSED selects
+    import numpy as np
+    rng = np.random.default_rng(0)
+    X = torch.as_tensor(rng.random((B, N, 8)) * 0.3 + 0.3).to(dev)
+    y = torch.as_tensor(rng.random((B, N))).to(dev)
+    ws = ops.fit_workspace(B, N, 8, dev)
+    for _ in range(reps):
+        raw = ops.init_hypers(y, ops.MATERN32)
+        alpha, flags = ops.fit(X, y, ops.MATERN32, raw, iters=1, workspace=ws)
+    torch.cuda.synchronize()
+    print("flags", int(flags.sum()), "alpha0", float(alpha[0, 0]))
+    sys.exit(0)
 g = torch.Generator(device=dev); g.manual_seed(0)
 Q = torch.randn((B, N, 64), dtype=torch.float64, device=dev, generator=g)
 A0 = Q @ Q.transpose(1, 2) / 64 + 0.5 * torch.eye(N, dtype=torch.float64, device=dev)

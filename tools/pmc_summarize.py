@@ -35,6 +35,8 @@ def main(src, dst, B=633, N=784, mode="invert"):
                 a[0] += 1
                 a[1] += float(row["Counter_Value"])
     what = (f"one batched inversion of {B} SPD matrices of order {N}" if mode == "invert" else
+            f"gpsr_fit with one Adam iteration (two evaluations per GP) of {B} GPs with n = {N}, Matern-3/2, "
+            f"GPSR_FUSED={os.environ.get('GPSR_FUSED', '0')}" if mode == "fit1" else
             f"one whole fit evaluation (covariance, sweeps, alpha, gradient statistics) of {B} GPs with n = {N}, Matern-3/2")
     out = {"command": "tools/pmc_run.sh: rocprofv3 --pmc <group> --kernel-trace, one counter group per run, on "
                       f"tools/pmc_invert.py {B} {N} 1 {mode} ({what})",
