@@ -201,10 +201,11 @@ int gpsr_set_split_small(int on);
  * Opt-in, off by default (GPSR_FUSED=1 in the environment turns it on): the fused per-GP route of gpsr_fit
  * (k_fit_fused; no counterpart in the reference).  ONE launch runs the whole fit -- one workgroup per GP through
  * covariance, sweep, alpha, gradient statistics and the Adam step of every iteration, a persistent grid of two
- * workgroups per CU walking the batch, the matrix and panels in a per-workgroup-slot workspace that stays in L2 /
- * Infinity Cache -- instead of ~650 launches that each stream the whole batch through HBM.  Same role functions on the
- * same data in the same order: bit-identical to the launch-per-step route.  Used when on and d == 8, N >= 224.
- * Measured slower than the default route on MI355X, hence opt-in.  Process-wide, returns the
+ * workgroups per CU walking the batch, the matrix and panels in a per-workgroup-slot workspace (min(B, 2 x CUs) slots
+ * instead of B) -- instead of ~650 launches over the whole batch.  Same role functions on the same data in the same
+ * order: bit-identical to the launch-per-step route.  Used when on and d == 8, N >= 224.  Measured on MI355X it is
+ * slower and moves MORE bytes through HBM than the default route, hence opt-in: its use is the
+ * small workspace.  Process-wide, returns the
  * previous setting.  gpsr_fit_workspace_bytes / gpsr_predict_pixels_workspace_bytes follow the current setting (the
  * fused route needs min(B, 2 x CUs) matrix slots + 32 bytes per GP): size the workspace after setting it.
  */

@@ -239,15 +239,11 @@ static size_t fit_ws_bytes1(int B, int N) {
          2 * align256((size_t)B * 4 * 4);
 }
 // ---- fused per-GP route (k_fit_fused; opt-in): ONE launch per fit, one workgroup per GP, a persistent grid of two
-// workgroups per CU; the workspace is per SLOT (resident workgroup), not per GP.  Built to take the n = 324 path
-// (BASELINE config 4) off HBM -- the launch-per-step route streams the whole batch through HBM a dozen times per
-// evaluation -- and it does (0.9 GiB of workspace instead of 19 GiB for 10 800 GPs, re-read out of L2 / Infinity Cache),
-// but measured on MI355X it is SLOWER: 2.0 us per GP-evaluation against 1.585 (10 800 GPs of n = 324, Matern-3/2).
-// tools/fused_trace.py shows why: with two workgroups per CU (LDS and the 128-register budget allow no more) nothing
-// hides a role's own latencies -- the first DMA chunk, the drain of its stores before the next role may read them,
-// the global loads of the gradient pass -- which the launch-per-step route hides behind the other 10 000 workgroups of
-// the launch.  Kept as a tested, bit-identical, opt-in route: gpsr_set_fused(1) / GPSR_FUSED=1;
-// GPSR_FUSED_STAGGER is a tuning switch.
+// workgroups per CU; the workspace is per SLOT (resident workgroup), not per GP (0.9 GiB instead of 19 GiB for 10 800 GPs
+// of n = 324).  Built to take the n = 324 path (BASELINE config 4) off HBM; measured on MI355X it does neither that
+// (7.9 MB of HBM traffic per GP-evaluation against 4.5 MB, profiles/r03_pmc_fit1*_10800x324.json) nor run faster (2.0 us
+// per GP-evaluation against 1.585): gpsr_kernels.hpp and DESIGN.md section 9 say why.  Kept as a tested, bit-identical,
+// opt-in route: gpsr_set_fused(1) / GPSR_FUSED=1; GPSR_FUSED_STAGGER is a tuning switch.
 static int env_int(const char* name, int dflt) { const char* v = getenv(name); return v ? atoi(v) : dflt; }
 static int g_fused_mode = env_int("GPSR_FUSED", 0) ? 1 : 0;
 static const int g_fused_stagger = env_int("GPSR_FUSED_STAGGER", 24);

@@ -1929,16 +1929,19 @@ __global__ void k_adam(float* __restrict__ raw, float* __restrict__ m1, float* _
           bc2_sqrt, one_minus_b1, b2, one_minus_b2, eps);
 }
 
-// ---------------------------------------------------------------- fused per-GP fit (large batches of small matrices)
-// The launch-per-step route above passes the WHOLE batch through HBM a dozen times per evaluation (n = 324: 4.9-6.7 MB of
-// traffic per GP-evaluation against 0.6 MB for the lower triangle itself) and its launches are, one after the other,
-// HBM-bound (build, panel, updates), latency-bound (pivot) or VALU-bound (build, gradient): the chip only ever does one
-// of the three.  Here ONE workgroup owns one GP for its whole fit -- covariance, sweep, alpha, gradient statistics and
-// the Adam step of every iteration, no launch boundary and no inter-workgroup dependence anywhere -- and a persistent
-// grid of two workgroups per CU walks the batch.  The workgroups drift apart in phase, so pivots (latency), tile
-// products (MFMA / L2) and pair loops (VALU) of different GPs overlap on a CU; the matrix, panels and pivot factors live
-// in a per-SLOT workspace (slot = resident workgroup: 512 x 1.9 MB at N = 336 instead of B x 1.9 MB) that the same
-// workgroup re-reads within microseconds of writing it, i.e. out of L2 / Infinity Cache instead of HBM.
+// ---------------------------------------------------------------- fused per-GP fit (opt-in experiment)
+// The launch-per-step route above passes the WHOLE batch through HBM a dozen times per evaluation (n = 324: ~4.5 MB of
+// counted traffic per GP-evaluation against 0.6 MB for the lower triangle itself) and its launches are, one after the
+// other, HBM-bound (build, panel, updates), latency-bound (pivot) or VALU-bound (build, gradient).  Here ONE workgroup
+// owns one GP for its whole fit -- covariance, sweep, alpha, gradient statistics and the Adam step of every iteration, no
+// launch boundary and no inter-workgroup dependence anywhere -- and a persistent grid of two workgroups per CU walks the
+// batch; the matrix, panels and pivot factors live in a per-SLOT workspace (slot = resident workgroup: 512 x 1.9 MB at
+// N = 336 instead of B x 1.9 MB).  The idea was that a workgroup re-reads within microseconds what it wrote, out of L2 /
+// Infinity Cache.  MEASURED (MI355X, 10 800 GPs of n = 324): it does not -- 7.9 MB of HBM traffic per GP-evaluation
+// against 4.5 MB (the 0.9 GB of live slots exceed the 256 MB Infinity Cache, every store goes through to HBM, and the
+// out-of-line roles add their callee-saved-register traffic) -- and it is slower, 2.0 against 1.585 us per
+// GP-evaluation, because two workgroups per CU hide none of a role's own latencies.  Kept as a
+// tested, bit-identical option and as the reason every kernel body is a role function.
 // The body is the sequence of role functions the launch wrappers above execute, on the same data in the same order:
 // results are bit-identical to the launch-per-step route (tests/test_gpu_kernels.py::test_fit_fused_bit_identical).
 // Within a workgroup a role's global stores are ordered before the next role's loads by __syncthreads() (workgroup-

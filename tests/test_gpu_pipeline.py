@@ -226,6 +226,22 @@ def test_set14_x3_chain_per_image_vs_oracle_chain_goldens(golden_dir):
     assert dd.max() <= 1 and (dd == 0).mean() > 0.9999, (dd.max(), (dd == 0).mean())
 
 
+def test_chained_batch_under_a_small_workspace_budget_bit_identical():
+    """fit_predict_chains respects max_workspace_bytes: with a budget that holds 3 GPs the 7 chains of a call advance in
+    groups of 3 per link (the chains of a link are independent GPs), and the result is the unchunked one to the bit."""
+    from super_resolution_amd import kernels as K, ops
+    from super_resolution_amd.gprsr import GPRSR, ColorSpace
+    imgs = [ops.u8_to_unit(to_dev(_lr_image(40 + 3 * k, 44 + 2 * k, 50 + k))) for k in range(7)]
+    per = ops._lib.load().gpsr_fit_workspace_bytes(1, 324, 8)
+    outs = []
+    for budget in (48 << 30, 3 * per + 1024):
+        g = GPRSR(2, K.matern32_kernel, ColorSpace.GRAYSCALE, warm_start="chain_per_image", iters=6, max_workspace_bytes=budget)
+        assert g._gp.chunk_size(7, 324, 8) == (7 if budget > (1 << 30) else 3)
+        outs.append(g.apply_for_channel_device(imgs))
+        assert all(int(f.sum()) == 0 for f in g.stats.flags)
+    assert all(torch.equal(a, b) for a, b in zip(*outs))
+
+
 @pytest.mark.parametrize("kid,s,chunk", [(3, 2, 0), (0, 3, 3), (2, 2, 4)])
 def test_fused_predict_pixels_entry_point_equals_staged_path(kid, s, chunk):
     """gpsr_predict_pixels (one C call: gather -> init -> fit -> predict -> combine, chunked)
