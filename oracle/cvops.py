@@ -11,7 +11,8 @@ oracle reproduces img_001_SRF_2_GPR_matern52_gray.png BIT FOR BIT; bgr2yuv /
 yuv2bgr and the uint8 resize_cubic by the reference's colour outputs and uint8
 downscales (every pixel at x2, x4 and 1/2; 99.89 % at x3); bgr2ycrcb / ycrcb2bgr,
 gaussian_blur(3, 1), gaussian_blur_u8 and filter2d_3x3 by its AGPR outputs.
-Still "parity unpinned" (no reference-held vector): psnr / ssim.
+psnr / ssim are pinned by scikit-image 0.18.3 itself (tests/golden/skimage_metrics.json, made by running
+skimage.metrics under the image's /opt/conda Python 3.9: agreement to 4e-15).
 
 Call sites restated:
   resize_cubic        cv.resize(..., INTER_CUBIC)            gprsr.py:60-61,106; agpr.py:103,152-153,163,205,246

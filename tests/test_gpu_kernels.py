@@ -532,6 +532,20 @@ def test_metrics_kernel_vs_oracle(H, W, crop):
     assert np.array_equal(got, ops.metrics(to_dev(a), to_dev(b), crop).cpu().numpy())
 
 
+def test_metrics_match_real_scikit_image(golden_dir):
+    """gpsr_metrics against scikit-image 0.18.3 ITSELF (tests/golden/skimage_metrics.json: skimage.metrics on committed
+    fixture pairs, tests/golden/make_skimage_metric_goldens.py): PSNR and SSIM of evaluation.py:83-98 to 1e-10."""
+    import json
+    from PIL import Image
+    from super_resolution_amd import ops
+    g = json.load(open(os.path.join(golden_dir, "skimage_metrics.json")))
+    for p in g["pairs"]:
+        a = np.array(Image.open(os.path.join(golden_dir, p["hr"])))
+        b = np.array(Image.open(os.path.join(golden_dir, p["upscaled"])))
+        got = ops.metrics(to_dev(a), to_dev(b), p["crop"]).cpu().numpy()
+        assert abs(got[0] - p["psnr"]) < 1e-10 and abs(got[1] - p["ssim"]) < 1e-10 and abs(got[2] - p["mse"]) < 1e-9, (p, got)
+
+
 @pytest.mark.parametrize("kid,n", [(3, 324), (0, 784)])
 def test_near_singular_patch_needs_no_jitter(kid, n):
     """Failure semantics (SURVEY.md 5.9 "Solver"): GPyTorch's psd_safe_cholesky adds jitter 1e-8 / 1e-7 / 1e-6 only
