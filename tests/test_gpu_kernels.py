@@ -1,6 +1,8 @@
 """GPU parity tests, kernel by kernel, through the C ABI (libgpsr.so) against the
 CPU oracle.  Bars: bit-exact for the index/copy kernels (gather, combine);
 float64 tolerances written at each assert for the numerical kernels."""
+import os
+
 import numpy as np
 import pytest
 import torch
