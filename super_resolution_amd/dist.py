@@ -35,19 +35,27 @@ def deal_chains(lens, world):
 
 # Diagnostics of the exchange (bench.py --gpus N prints them per rank, so that a scaling run explains itself): number
 # of calls, bytes this rank contributed / received, and -- on CUDA tensors -- HIP events around the collective.
-STATS = {"calls": 0, "bytes_sent": 0, "bytes_received": 0, "rows_owned": 0, "events": []}
+STATS = {"calls": 0, "bytes_sent": 0, "bytes_received": 0, "rows_owned": 0, "events": [], "ms": 0.0}
+_MAX_PENDING_EVENTS = 32      # a process that never asks for the summary must not pile up event pairs
 
 
 def reset_stats():
-    STATS.update(calls=0, bytes_sent=0, bytes_received=0, rows_owned=0, events=[])
+    STATS.update(calls=0, bytes_sent=0, bytes_received=0, rows_owned=0, events=[], ms=0.0)
+
+
+def _fold_events(keep):
+    """Move the oldest event pairs beyond `keep` into the millisecond total (they are waited for: long finished)."""
+    ev = STATS["events"]
+    while len(ev) > keep:
+        a, b = ev.pop(0)
+        b.synchronize()
+        STATS["ms"] += a.elapsed_time(b)
 
 
 def stats_summary():
     """-> dict with the counters and the total milliseconds inside the collectives (synchronises on their events)."""
-    ms = 0.0
-    for a, b in STATS["events"]:
-        b.synchronize()
-        ms += a.elapsed_time(b)
+    _fold_events(0)
+    ms = STATS["ms"]
     return {"exchange_calls": STATS["calls"], "bytes_sent": STATS["bytes_sent"], "bytes_received": STATS["bytes_received"],
             "rows_owned": STATS["rows_owned"], "exchange_ms": round(ms, 3)}
 
@@ -107,6 +115,7 @@ def exchange_rows(locals_, owned, B, rank, world, group=None, force_collective=F
     if ev is not None:
         ev[1].record()
         STATS["events"].append(ev)
+        _fold_events(_MAX_PENDING_EVENTS)
     STATS["calls"] += 1
     STATS["bytes_sent"] += cap * row_bytes
     STATS["bytes_received"] += world * cap * row_bytes
