@@ -100,6 +100,10 @@ def load():
         raise RuntimeError(
             f"{LIB_PATH} not found: the HIP extension is the only compute path "
             "(run `python -c 'import __graft_entry__ as g; g.build()'`)")
+    # torch first: the process must hold ONE HIP runtime, the copy torch ships (it owns the device memory and the streams
+    # this library is handed).  Loaded before torch, libgpsr.so would bring /opt/rocm's libamdhip64 with it, torch its
+    # own afterwards, and the launches of whichever runtime comes second fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the symbol is not exported

@@ -585,3 +585,17 @@ def test_near_singular_patch_needs_no_jitter(kid, n):
     m_got = ops.predict(Xd, to_dev(Xs[None]), alpha, rd, kid)[0].cpu().numpy()
     # two CPU routes (Cholesky solve vs explicit inverse) differ by 8e-6 / 4e-5 here: 1e-3 is a quarter grey level
     assert np.abs(m_got - m_want).max() < 1e-3, np.abs(m_got - m_want).max()
+
+
+def test_library_loaded_before_torch_still_shares_one_hip_runtime():
+    """`python __graft_entry__.py smoke` loads libgpsr.so (build()) before anything imports torch.  Two HIP runtimes in
+    one process (/opt/rocm's, pulled in by the library, and torch's own) leave the second without a device, so
+    _lib.load() imports torch first; a fresh process in that order must be able to launch."""
+    import subprocess
+    import sys
+    code = ("from super_resolution_amd import _lib; _lib.load(); import torch; from super_resolution_amd import ops; "
+            "x = torch.arange(64, dtype=torch.uint8, device='cuda'); y = ops.u8_to_unit(x); torch.cuda.synchronize(); "
+            "assert abs(float(y[51]) - 51 / 255) < 1e-15; print('one-runtime-ok')")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300,
+                       cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    assert r.returncode == 0 and "one-runtime-ok" in r.stdout, r.stdout[-1000:] + r.stderr[-2000:]
